@@ -1,0 +1,690 @@
+// abc_context.hip -- context construction (device tables) and the extern "C" entry points of
+// libabc_hip.so declared in include/abc_hip.h.
+//
+// abc_hip_ctx_create replaces SealCiphertextFactory::setupSealContext
+// (src/runtime/SealCiphertextFactory.cpp:72-100): it fixes the modulus chain, builds the NTT twiddle
+// tables (bit-reversed powers of the minimal primitive 2N-th root, with Shoup quotients), the BEHZ
+// auxiliary bases {B, m_sk, gamma, m~ = 2^32} and every scalar constant the kernels need, and uploads
+// them once; nothing is recomputed per operation.
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/abc_hip.h"
+#include "abc_context.hpp"
+#include "abc_host_math.hpp"
+
+namespace abc {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+int ensure_workspace(abc_hip_ctx *c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return 0;
+  if (c->ws) {
+    ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->ws);
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+  }
+  size_t want = bytes + bytes / 8;
+  ABC_HIP_CHECK(hipMalloc(&c->ws, want));
+  c->ws_bytes = want;
+  return 0;
+}
+
+static Mod make_mod(uint64_t q, int logn, bool ntt) {
+  using namespace host;
+  Mod m{};
+  m.q = q;
+  m.two_q = 2 * q;
+  const int k = bitlen(q);
+  m.bits = (u32)k;
+  m.shift = (u32)(k - 1);
+  m.mu = (uint64_t)((((u128)1) << (k + 63)) / q);
+  m.qd = (double)q;
+  m.qinv = 1.0 / (double)q;
+  if (ntt) {
+    const uint64_t n = 1ull << logn;
+    m.inv_n = invmod(n % q, q);
+    m.inv_n_s = shoup(m.inv_n, q);
+  }
+  return m;
+}
+
+static void fill_twiddles(uint64_t q, int logn, uint64_t *dst /*[4][N]*/) {
+  using namespace host;
+  const size_t n = (size_t)1 << logn;
+  const uint64_t psi = min_primitive_root(2 * n, q);
+  uint64_t *tw = dst, *tws = dst + n, *itw = dst + 2 * n, *itws = dst + 3 * n;
+  uint64_t p = 1;
+  for (size_t i = 0; i < n; i++) {
+    tw[bitrev((uint32_t)i, logn)] = p;
+    p = mulmod(p, psi, q);
+  }
+  // inverses: psi^-e = -psi^(N-e); batch through one inversion of psi
+  const uint64_t ipsi = invmod(psi, q);
+  p = 1;
+  for (size_t i = 0; i < n; i++) {
+    itw[bitrev((uint32_t)i, logn)] = p;
+    p = mulmod(p, ipsi, q);
+  }
+  for (size_t i = 0; i < n; i++) {
+    tws[i] = shoup(tw[i], q);
+    itws[i] = shoup(itw[i], q);
+  }
+}
+
+static int build_context(abc_hip_ctx *c) {
+  using namespace host;
+  const int logn = c->logn, K = c->K, L = c->L;
+  const size_t N = (size_t)c->n;
+  const bool bfv = (c->scheme == ABC_HIP_SCHEME_BFV);
+  std::vector<uint64_t> qs(c->primes.begin(), c->primes.begin() + L);
+  const uint64_t qsp = c->primes[K - 1];
+  DevConst &k = c->h_cst;
+  std::memset(&k, 0, sizeof(k));
+
+  // ---- modulus table ----
+  c->mod_values.assign(c->primes.begin(), c->primes.end());
+  std::vector<uint64_t> Bp;
+  uint64_t m_sk = 0, gamma = 0;
+  if (bfv) {
+    // BEHZ auxiliary base sizes as in SEAL's RNSTool
+    int nB = L;
+    if (32 + bitlen(c->t) + prod_bitlen(qs) >= 61 * L + 61) nB++;
+    auto aux = ntt_primes(N, 61, (size_t)nB + 2);
+    m_sk = aux[0];
+    gamma = aux[1];
+    Bp.assign(aux.begin() + 2, aux.end());
+    c->nB = nB;
+    c->nBsk = nB + 1;
+    for (uint64_t b : Bp) c->mod_values.push_back(b);
+    c->mod_values.push_back(m_sk);
+    c->mod_values.push_back(gamma);
+    c->mod_values.push_back(c->t);
+  }
+  const int nmods = (int)c->mod_values.size();
+  const int id_bsk = K, id_gamma = K + c->nBsk, id_t = K + c->nBsk + 1;
+  c->h_mods.clear();
+  std::vector<uint64_t> h_tw((size_t)nmods * 4 * N, 0);
+  for (int i = 0; i < nmods; i++) {
+    const bool ntt = !(bfv && i == id_gamma);
+    c->h_mods.push_back(make_mod(c->mod_values[i], logn, ntt));
+    if (ntt) fill_twiddles(c->mod_values[i], logn, h_tw.data() + (size_t)i * 4 * N);
+  }
+
+  // ---- key / modulus switching constants ----
+  for (int j = 0; j < L; j++) {
+    const uint64_t q = qs[j];
+    k.inv_special[j] = invmod(qsp % q, q);
+    k.inv_special_s[j] = shoup(k.inv_special[j], q);
+    k.special_mod_q[j] = qsp % q;
+  }
+  for (int l = 1; l < L; l++)
+    for (int j = 0; j < l; j++) {
+      k.inv_qlast[l][j] = invmod(qs[l] % qs[j], qs[j]);
+      k.inv_qlast_s[l][j] = shoup(k.inv_qlast[l][j], qs[j]);
+    }
+
+  std::vector<uint32_t> slot_map;
+  if (bfv) {
+    const uint64_t t = c->t;
+    k.t = t;
+    k.q_mod_t = prod_mod(qs, t);
+    k.upper_half_threshold = (t + 1) >> 1;
+    for (int i = 0; i < L; i++) {
+      const uint64_t q = qs[i];
+      // floor(Q/t) mod q_i = -(Q mod t) * t^-1 mod q_i
+      k.coeff_div_plain[i] = mulmod(negmod(k.q_mod_t, q), invmod(t % q, q), q);
+      k.upper_half_increment[i] = q - t;
+    }
+    // BatchEncoder slot -> coefficient-index map: slot i of row 0 <-> evaluation at psi^(3^i)
+    slot_map.resize(N);
+    const size_t row = N >> 1, m = N << 1;
+    uint64_t pos = 1;
+    for (size_t i = 0; i < row; i++) {
+      slot_map[i] = bitrev((uint32_t)((pos - 1) >> 1), logn);
+      slot_map[row | i] = bitrev((uint32_t)((m - pos - 1) >> 1), logn);
+      pos = (pos * 3) & (m - 1);
+    }
+    // ---- BEHZ ----
+    const int nB = c->nB, nBsk = c->nBsk;
+    const uint64_t mt = 1ull << 32;
+    std::vector<uint64_t> bsk(Bp);
+    bsk.push_back(m_sk);
+    k.nq = L; k.nB = nB; k.nBsk = nBsk;
+    auto punct_mod = [&](const std::vector<uint64_t> &base, int skip, uint64_t p) {
+      uint64_t v = 1 % p;
+      for (int i = 0; i < (int)base.size(); i++)
+        if (i != skip) v = mulmod(v, base[i] % p, p);
+      return v;
+    };
+    for (int i = 0; i < L; i++) {
+      const uint64_t q = qs[i];
+      k.mtilde_mod_q[i] = mt % q;
+      k.inv_punct_q[i] = invmod(punct_mod(qs, i, q), q);
+      for (int j = 0; j < nBsk; j++) k.q_to_bsk[j][i] = punct_mod(qs, i, bsk[j]);
+      k.q_to_mtilde[i] = punct_mod(qs, i, mt);
+      k.q_to_t[i] = punct_mod(qs, i, t);
+      k.q_to_gamma[i] = punct_mod(qs, i, gamma);
+      k.B_mod_q[i] = prod_mod(Bp, q);
+      k.t_mod_q[i] = t % q;
+      k.tgamma_mod_q[i] = mulmod(t % q, gamma % q, q);
+      for (int b = 0; b < nB; b++) k.B_to_q[i][b] = punct_mod(Bp, b, q);
+    }
+    k.neg_inv_q_mod_mtilde = negmod(invmod(prod_mod(qs, mt), mt), mt);
+    for (int j = 0; j < nBsk; j++) {
+      const uint64_t p = bsk[j];
+      k.q_mod_bsk[j] = prod_mod(qs, p);
+      k.inv_q_mod_bsk[j] = invmod(k.q_mod_bsk[j], p);
+      k.inv_mtilde_mod_bsk[j] = invmod(mt % p, p);
+      k.t_mod_bsk[j] = t % p;
+    }
+    for (int b = 0; b < nB; b++) {
+      k.inv_punct_B[b] = invmod(punct_mod(Bp, b, Bp[b]), Bp[b]);
+      k.B_to_msk[b] = punct_mod(Bp, b, m_sk);
+    }
+    k.inv_B_mod_msk = invmod(prod_mod(Bp, m_sk), m_sk);
+    k.neg_inv_q_mod_t = negmod(invmod(prod_mod(qs, t), t), t);
+    k.neg_inv_q_mod_gamma = negmod(invmod(prod_mod(qs, gamma), gamma), gamma);
+    k.inv_gamma_mod_t = invmod(gamma % t, t);
+    k.gamma = gamma;
+  }
+
+  // ---- upload ----
+  ABC_HIP_CHECK(hipMalloc(&c->d_mods, nmods * sizeof(Mod)));
+  ABC_HIP_CHECK(hipMemcpy(c->d_mods, c->h_mods.data(), nmods * sizeof(Mod), hipMemcpyHostToDevice));
+  ABC_HIP_CHECK(hipMalloc(&c->d_tw, h_tw.size() * 8));
+  ABC_HIP_CHECK(hipMemcpy(c->d_tw, h_tw.data(), h_tw.size() * 8, hipMemcpyHostToDevice));
+  ABC_HIP_CHECK(hipMalloc(&c->d_cst, sizeof(DevConst)));
+  ABC_HIP_CHECK(hipMemcpy(c->d_cst, &k, sizeof(DevConst), hipMemcpyHostToDevice));
+  if (bfv) {
+    ABC_HIP_CHECK(hipMalloc(&c->d_slot_map, N * 4));
+    ABC_HIP_CHECK(hipMemcpy(c->d_slot_map, slot_map.data(), N * 4, hipMemcpyHostToDevice));
+  }
+  DevCtx &dc = c->dc;
+  dc.mods = c->d_mods; dc.tw = c->d_tw; dc.cst = c->d_cst; dc.slot_map = c->d_slot_map;
+  dc.logn = logn; dc.n = (int)N; dc.K = K; dc.L = L;
+  dc.id_bsk = id_bsk; dc.id_t = id_t; dc.id_gamma = id_gamma; dc.id_mtilde = -1;
+  return 0;
+}
+
+// ---- rotation bookkeeping (GaloisTool::get_elt_from_step, util::naf) ----
+static uint32_t elt_from_step(const abc_hip_ctx *c, int step) {
+  const uint32_t n = (uint32_t)c->n;
+  const uint64_t m = 2ull * n;
+  if (step == 0) return (uint32_t)(m - 1);
+  const bool neg = step < 0;
+  const uint32_t pos = (uint32_t)(neg ? -step : step);
+  if (pos >= (n >> 1)) return 0;
+  const int s = neg ? (int)(n >> 1) - (int)pos : (int)pos;
+  uint64_t g = 1;
+  for (int i = 0; i < s; i++) g = (g * 3) & (m - 1);
+  return (uint32_t)g;
+}
+
+static std::vector<int> naf(int value) {
+  std::vector<int> out;
+  const bool sign = value < 0;
+  value = std::abs(value);
+  for (int i = 0; value; i++) {
+    const int zi = (value & 1) ? 2 - (value & 3) : 0;
+    value = (value - zi) >> 1;
+    if (zi) out.push_back((sign ? -zi : zi) * (1 << i));
+  }
+  return out;
+}
+
+static int apply_galois(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, uint32_t elt, size_t count) {
+  auto it = c->d_galois.find(elt);
+  if (it == c->d_galois.end()) { set_error("Galois key not present"); return 1; }
+  if (!count) return 0;
+  const size_t N = (size_t)c->n, pw = (size_t)nl * N;
+  const bool ntt_form = (c->scheme == ABC_HIP_SCHEME_CKKS);
+  // g(c0), g(c1) into a private buffer (keyswitch_generic uses c->ws)
+  u64 *g = nullptr;
+  ABC_HIP_CHECK(hipMalloc(&g, count * 2 * pw * 8));
+  int rc = launch_galois(c, in, g, nl, count * 2, elt, ntt_form);
+  // out = (g(c0) + ks0, ks1) with ks = KeySwitch(g(c1))
+  if (!rc) rc = keyswitch_generic(c, g + pw, 2 * pw, it->second, out, nl, count, g, 2 * pw, false);
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("apply_galois: sync failed"); rc = 1; }
+  (void)hipFree(g);
+  return rc;
+}
+
+static int rotate(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, int steps, size_t count) {
+  const size_t bytes = count * 2 * nl * (size_t)c->n * 8;
+  if (steps == 0) {
+    if (in != out) ABC_HIP_CHECK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+  }
+  const uint32_t elt = elt_from_step(c, steps);
+  if (!elt) { set_error("step count too large"); return 1; }
+  if (c->d_galois.count(elt)) {
+    if (in != out) return apply_galois(c, in, out, nl, elt, count);
+    u64 *tmp = nullptr;
+    ABC_HIP_CHECK(hipMalloc(&tmp, bytes));
+    int rc = apply_galois(c, in, tmp, nl, elt, count);
+    if (!rc) ABC_HIP_CHECK(hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (!rc) ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+    (void)hipFree(tmp);
+    return rc;
+  }
+  const std::vector<int> terms = naf(steps);
+  if (terms.size() == 1) { set_error("Galois key not present"); return 1; }
+  u64 *bufA = nullptr, *bufB = nullptr;
+  ABC_HIP_CHECK(hipMalloc(&bufA, bytes));
+  ABC_HIP_CHECK(hipMalloc(&bufB, bytes));
+  ABC_HIP_CHECK(hipMemcpyAsync(bufA, in, bytes, hipMemcpyDeviceToDevice, c->stream));
+  int rc = 0;
+  for (int s : terms) {
+    if ((size_t)std::abs(s) == ((size_t)c->n >> 1)) continue;
+    rc = rotate(c, bufA, bufB, nl, s, count);
+    if (rc) break;
+    std::swap(bufA, bufB);
+  }
+  if (!rc) ABC_HIP_CHECK(hipMemcpyAsync(out, bufA, bytes, hipMemcpyDeviceToDevice, c->stream));
+  if (!rc) ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  (void)hipFree(bufA); (void)hipFree(bufB);
+  return rc;
+}
+
+static int relinearize(abc_hip_ctx *c, const u64 *ct3, u64 *out2, int nl, size_t count) {
+  if (!c->d_relin) { set_error("relinearize: no relinearisation key"); return 1; }
+  const size_t pw = (size_t)nl * c->n;
+  // target = c2 (poly 2 of each size-3 ciphertext); addend = (c0, c1)
+  return keyswitch_generic(c, ct3 + 2 * pw, 3 * pw, c->d_relin, out2, nl, count, ct3, 3 * pw, true);
+}
+
+}  // namespace abc
+
+using namespace abc;
+
+#define CTX_GUARD(c)                                   \
+  do {                                                 \
+    if (!(c)) { set_error("null context"); return 1; } \
+    if (hipSetDevice((c)->device) != hipSuccess) { set_error("hipSetDevice failed"); return 1; } \
+  } while (0)
+
+extern "C" {
+
+const char *abc_hip_last_error(void) { return g_err.c_str(); }
+
+int abc_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int abc_hip_default_bfv_primes(size_t n, uint64_t *out) {
+  // the 128-bit-security default chains of SEAL 3.6 (CoeffModulus::BFVDefault)
+  static const uint64_t p1024[] = {0x7e00001ull};
+  static const uint64_t p2048[] = {0x3fffffff000001ull};
+  static const uint64_t p4096[] = {0xffffee001ull, 0xffffc4001ull, 0x1ffffe0001ull};
+  static const uint64_t p8192[] = {0x7fffffd8001ull, 0x7fffffc8001ull, 0xfffffffc001ull, 0xffffff6c001ull, 0xfffffebc001ull};
+  static const uint64_t p16384[] = {0xfffffffd8001ull,  0xfffffffa0001ull,  0xfffffff00001ull,  0x1fffffff68001ull, 0x1fffffff50001ull,
+                                    0x1ffffffee8001ull, 0x1ffffffea0001ull, 0x1ffffffe88001ull, 0x1ffffffe48001ull};
+  static const uint64_t p32768[] = {0x7fffffffe90001ull, 0x7fffffffbf0001ull, 0x7fffffffbd0001ull, 0x7fffffffba0001ull,
+                                    0x7fffffffaa0001ull, 0x7fffffffa50001ull, 0x7fffffff9f0001ull, 0x7fffffff7e0001ull,
+                                    0x7fffffff770001ull, 0x7fffffff380001ull, 0x7fffffff330001ull, 0x7fffffff2d0001ull,
+                                    0x7fffffff170001ull, 0x7fffffff150001ull, 0x7ffffffef00001ull, 0xfffffffff70001ull};
+  const uint64_t *src = nullptr;
+  int cnt = 0;
+  switch (n) {
+    case 1024: src = p1024; cnt = 1; break;
+    case 2048: src = p2048; cnt = 1; break;
+    case 4096: src = p4096; cnt = 3; break;
+    case 8192: src = p8192; cnt = 5; break;
+    case 16384: src = p16384; cnt = 9; break;
+    case 32768: src = p32768; cnt = 16; break;
+    default: set_error("no default BFV coefficient modulus for this ring degree"); return -1;
+  }
+  for (int i = 0; i < cnt; i++) out[i] = src[i];
+  return cnt;
+}
+
+uint64_t abc_hip_plain_modulus_batching(size_t n, int bits) {
+  try {
+    return host::ntt_primes(n, bits, 1)[0];
+  } catch (const std::exception &e) {
+    set_error(e.what());
+    return 0;
+  }
+}
+
+int abc_hip_create_primes(size_t n, const int *bit_sizes, int count, uint64_t *out) {
+  try {
+    std::map<int, std::vector<uint64_t>> table;
+    for (int i = 0; i < count; i++) table[bit_sizes[i]];
+    for (auto &kv : table) {
+      size_t need = 0;
+      for (int i = 0; i < count; i++) need += (bit_sizes[i] == kv.first);
+      kv.second = host::ntt_primes(n, kv.first, need);
+    }
+    for (int i = 0; i < count; i++) {  // hand out from the back (smallest first), as CoeffModulus::Create does
+      auto &v = table[bit_sizes[i]];
+      out[i] = v.back();
+      v.pop_back();
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    set_error(e.what());
+    return 1;
+  }
+}
+
+int abc_hip_ctx_create(int scheme, int logn, const uint64_t *primes, int nprimes, uint64_t plain_modulus, int device,
+                       abc_hip_ctx **out) {
+  if (!out) { set_error("null output pointer"); return 1; }
+  *out = nullptr;
+  if (scheme != ABC_HIP_SCHEME_BFV && scheme != ABC_HIP_SCHEME_CKKS) { set_error("unknown scheme"); return 1; }
+  if (logn < 10 || logn > 16) { set_error("logn must be in 10..16"); return 1; }
+  if (nprimes < 2 || nprimes > kMaxLimbs) { set_error("need 2..16 primes (data limbs + special prime)"); return 1; }
+  const uint64_t two_n = 2ull << logn;
+  for (int i = 0; i < nprimes; i++) {
+    if (primes[i] >> 60 || !host::is_prime(primes[i]) || primes[i] % two_n != 1) {
+      set_error("coefficient modulus primes must be < 2^60, prime and = 1 mod 2N");
+      return 1;
+    }
+    for (int j = 0; j < i; j++)
+      if (primes[j] == primes[i]) { set_error("coefficient modulus primes must be distinct"); return 1; }
+  }
+  if (scheme == ABC_HIP_SCHEME_BFV) {
+    if (!host::is_prime(plain_modulus) || plain_modulus % two_n != 1 || plain_modulus >> 32) {
+      set_error("plain modulus must be a prime = 1 mod 2N (batching) below 2^32");
+      return 1;
+    }
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device available"); return 1; }
+  if (device < 0 || device >= ndev) { set_error("device index out of range"); return 1; }
+  if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return 1; }
+  abc_hip_ctx *c = new abc_hip_ctx();
+  c->scheme = scheme; c->logn = logn; c->n = 1 << logn; c->K = nprimes; c->L = nprimes - 1; c->device = device;
+  c->primes.assign(primes, primes + nprimes);
+  c->t = (scheme == ABC_HIP_SCHEME_BFV) ? plain_modulus : 0;
+  int rc = 1;
+  try {
+    rc = build_context(c);
+  } catch (const std::exception &e) {
+    set_error(e.what());
+  }
+  if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)) {
+    set_error("hipEventCreate failed");
+    rc = 1;
+  }
+  if (rc) { abc_hip_ctx_destroy(c); return 1; }
+  *out = c;
+  return 0;
+}
+
+void abc_hip_ctx_destroy(abc_hip_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(c->d_mods); (void)hipFree(c->d_tw); (void)hipFree(c->d_cst); (void)hipFree(c->d_slot_map);
+  (void)hipFree(c->d_sk); (void)hipFree(c->d_pk); (void)hipFree(c->d_relin);
+  for (auto &kv : c->d_galois) (void)hipFree(kv.second);
+  (void)hipFree(c->ws);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  delete c;
+}
+
+int abc_hip_ctx_info(const abc_hip_ctx *c, int what) {
+  if (!c) return -1;
+  switch (what) {
+    case 0: return c->scheme;
+    case 1: return c->logn;
+    case 2: return c->K;
+    case 3: return c->L;
+    case 4: return c->device;
+    case 5: return c->nBsk;
+    default: return -1;
+  }
+}
+
+int abc_hip_set_stream(abc_hip_ctx *c, void *stream) {
+  CTX_GUARD(c);
+  c->stream = (hipStream_t)stream;
+  return 0;
+}
+int abc_hip_sync(abc_hip_ctx *c) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int abc_hip_malloc(abc_hip_ctx *c, void **d_ptr, size_t bytes) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
+  return 0;
+}
+int abc_hip_free(abc_hip_ctx *c, void *d_ptr) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  ABC_HIP_CHECK(hipFree(d_ptr));
+  return 0;
+}
+int abc_hip_memcpy_h2d(abc_hip_ctx *c, void *d, const void *h, size_t bytes) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int abc_hip_memcpy_d2h(abc_hip_ctx *c, void *h, const void *d, size_t bytes) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int abc_hip_memcpy_d2d(abc_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+// ---- keys ----
+int abc_hip_keygen(abc_hip_ctx *c, uint64_t seed) {
+  CTX_GUARD(c);
+  try {
+    return keygen(c, seed);
+  } catch (const std::exception &e) {
+    set_error(e.what());
+    return 1;
+  }
+}
+static int load_key(abc_hip_ctx *c, uint64_t **slot, const uint64_t *h, size_t words) {
+  if (!*slot) ABC_HIP_CHECK(hipMalloc(slot, words * 8));
+  ABC_HIP_CHECK(hipMemcpy(*slot, h, words * 8, hipMemcpyHostToDevice));
+  return 0;
+}
+int abc_hip_load_secret_key(abc_hip_ctx *c, const uint64_t *h) { CTX_GUARD(c); return load_key(c, &c->d_sk, h, (size_t)c->K * c->n); }
+int abc_hip_load_public_key(abc_hip_ctx *c, const uint64_t *h) { CTX_GUARD(c); return load_key(c, &c->d_pk, h, (size_t)2 * c->K * c->n); }
+int abc_hip_load_relin_key(abc_hip_ctx *c, const uint64_t *h) { CTX_GUARD(c); return load_key(c, &c->d_relin, h, c->key_words()); }
+int abc_hip_load_galois_key(abc_hip_ctx *c, uint32_t elt, const uint64_t *h) {
+  CTX_GUARD(c);
+  if (!(elt & 1) || elt >= 2u * (uint32_t)c->n) { set_error("Galois element must be odd and below 2N"); return 1; }
+  uint64_t *slot = c->d_galois.count(elt) ? c->d_galois[elt] : nullptr;
+  const bool fresh = (slot == nullptr);
+  if (load_key(c, &slot, h, c->key_words())) return 1;
+  c->d_galois[elt] = slot;
+  if (fresh) c->galois_order.push_back(elt);
+  return 0;
+}
+static int get_key(abc_hip_ctx *c, const uint64_t *d, uint64_t *h, size_t words, const char *what) {
+  if (!d) { set_error(std::string("key not present: ") + what); return 1; }
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  ABC_HIP_CHECK(hipMemcpy(h, d, words * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+int abc_hip_get_secret_key(abc_hip_ctx *c, uint64_t *h) { CTX_GUARD(c); return get_key(c, c->d_sk, h, (size_t)c->K * c->n, "secret"); }
+int abc_hip_get_public_key(abc_hip_ctx *c, uint64_t *h) { CTX_GUARD(c); return get_key(c, c->d_pk, h, (size_t)2 * c->K * c->n, "public"); }
+int abc_hip_get_relin_key(abc_hip_ctx *c, uint64_t *h) { CTX_GUARD(c); return get_key(c, c->d_relin, h, c->key_words(), "relin"); }
+int abc_hip_get_galois_key(abc_hip_ctx *c, uint32_t elt, uint64_t *h) {
+  CTX_GUARD(c);
+  auto it = c->d_galois.find(elt);
+  return get_key(c, it == c->d_galois.end() ? nullptr : it->second, h, c->key_words(), "galois");
+}
+int abc_hip_num_galois_keys(abc_hip_ctx *c) { return c ? (int)c->galois_order.size() : 0; }
+uint32_t abc_hip_galois_elt_at(abc_hip_ctx *c, int i) {
+  if (!c || i < 0 || i >= (int)c->galois_order.size()) return 0;
+  return c->galois_order[i];
+}
+uint32_t abc_hip_galois_elt_from_step(abc_hip_ctx *c, int step) { return c ? elt_from_step(c, step) : 0; }
+
+// ---- encode / encrypt / decrypt ----
+int abc_hip_batch_encode(abc_hip_ctx *c, const int64_t *v, uint64_t *p, size_t count) { CTX_GUARD(c); return batch_encode(c, v, p, count); }
+int abc_hip_batch_decode(abc_hip_ctx *c, const uint64_t *p, int64_t *v, size_t count) { CTX_GUARD(c); return batch_decode(c, p, v, count); }
+int abc_hip_encrypt(abc_hip_ctx *c, const uint64_t *p, uint64_t seed, uint64_t *ct, size_t count) { CTX_GUARD(c); return encrypt(c, p, seed, ct, count); }
+int abc_hip_decrypt(abc_hip_ctx *c, const uint64_t *ct, int size, int nl, uint64_t *p, size_t count) {
+  CTX_GUARD(c);
+  if (nl < 1 || nl > c->L) { set_error("decrypt: bad limb count"); return 1; }
+  return decrypt(c, ct, size, nl, p, count);
+}
+
+// ---- evaluator ----
+static int check_level(abc_hip_ctx *c, int nl) {
+  if (nl < 1 || nl > c->L) { set_error("limb count out of range for this context"); return 1; }
+  if (c->scheme == ABC_HIP_SCHEME_BFV && nl != c->L) { set_error("BFV ciphertexts live at the top level (nl = L)"); return 1; }
+  return 0;
+}
+int abc_hip_add(abc_hip_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, int size, int nl, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  return launch_addsub(c, a, b, out, nl, count * size, 0);
+}
+int abc_hip_sub(abc_hip_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, int size, int nl, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  return launch_addsub(c, a, b, out, nl, count * size, 1);
+}
+int abc_hip_negate(abc_hip_ctx *c, const uint64_t *a, uint64_t *out, int size, int nl, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  return launch_addsub(c, a, nullptr, out, nl, count * size, 2);
+}
+int abc_hip_multiply(abc_hip_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out3, int nl, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  if (c->scheme == ABC_HIP_SCHEME_CKKS) return launch_ckks_tensor(c, a, b, out3, nl, count);
+  return bfv_multiply(c, a, b, out3, count);
+}
+int abc_hip_relinearize(abc_hip_ctx *c, const uint64_t *ct3, uint64_t *out2, int nl, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  return relinearize(c, ct3, out2, nl, count);
+}
+int abc_hip_mul_relin(abc_hip_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out, int nl, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  if (!c->d_relin) { set_error("mul_relin: no relinearisation key"); return 1; }
+  if (c->scheme == ABC_HIP_SCHEME_CKKS) {
+    const int rc = ckks_mul_relin_fused(c, a, b, out, nl, count);
+    if (rc >= 0) return rc;
+  }
+  // generic path: size-3 product in a private buffer, then key switch
+  u64 *t3 = nullptr;
+  const size_t bytes = count * 3 * nl * (size_t)c->n * 8;
+  ABC_HIP_CHECK(hipMalloc(&t3, bytes ? bytes : 8));
+  int rc = (c->scheme == ABC_HIP_SCHEME_CKKS) ? launch_ckks_tensor(c, a, b, t3, nl, count) : bfv_multiply(c, a, b, t3, count);
+  if (!rc) rc = relinearize(c, t3, out, nl, count);
+  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("mul_relin: sync failed"); rc = 1; }
+  (void)hipFree(t3);
+  return rc;
+}
+int abc_hip_rotate(abc_hip_ctx *c, const uint64_t *in, uint64_t *out, int nl, int steps, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  return rotate(c, in, out, nl, steps, count);
+}
+int abc_hip_apply_galois(abc_hip_ctx *c, const uint64_t *in, uint64_t *out, int nl, uint32_t elt, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  if (in == out) { set_error("apply_galois: in-place not supported, use abc_hip_rotate"); return 1; }
+  return apply_galois(c, in, out, nl, elt, count);
+}
+int abc_hip_multiply_plain(abc_hip_ctx *c, const uint64_t *ct, const uint64_t *plain, size_t plain_stride, uint64_t *out, int size,
+                           int nl, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  if (c->scheme == ABC_HIP_SCHEME_CKKS) return ckks_multiply_plain(c, ct, plain, plain_stride, out, size, nl, count);
+  return bfv_multiply_plain(c, ct, plain, plain_stride, out, size, count);
+}
+int abc_hip_add_plain(abc_hip_ctx *c, const uint64_t *ct, const uint64_t *plain, size_t plain_stride, uint64_t *out, int size, int nl,
+                      size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  if (c->scheme == ABC_HIP_SCHEME_CKKS) return ckks_add_plain(c, ct, plain, plain_stride, out, size, nl, count, 0);
+  return bfv_addsub_plain(c, ct, plain, plain_stride, out, size, count, 0);
+}
+int abc_hip_sub_plain(abc_hip_ctx *c, const uint64_t *ct, const uint64_t *plain, size_t plain_stride, uint64_t *out, int size, int nl,
+                      size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  if (c->scheme == ABC_HIP_SCHEME_CKKS) return ckks_add_plain(c, ct, plain, plain_stride, out, size, nl, count, 1);
+  return bfv_addsub_plain(c, ct, plain, plain_stride, out, size, count, 1);
+}
+int abc_hip_rescale(abc_hip_ctx *c, const uint64_t *in, uint64_t *out, int size, int nl, size_t count) {
+  CTX_GUARD(c);
+  if (c->scheme != ABC_HIP_SCHEME_CKKS) { set_error("rescale is a CKKS operation"); return 1; }
+  if (check_level(c, nl)) return 1;
+  return launch_rescale(c, in, out, size, nl, count);
+}
+int abc_hip_mod_switch(abc_hip_ctx *c, const uint64_t *in, uint64_t *out, int size, int nl, size_t count) {
+  CTX_GUARD(c);
+  if (c->scheme != ABC_HIP_SCHEME_CKKS) { set_error("mod_switch is only implemented for CKKS"); return 1; }
+  if (check_level(c, nl)) return 1;
+  return launch_drop_last(c, in, out, size, nl, count);
+}
+
+// ---- raw pieces ----
+static int ntt_entry(abc_hip_ctx *c, uint64_t *d, int kind, int index, size_t count, bool fwd) {
+  int mid;
+  if (kind == 0) {
+    if (index < 0 || index >= c->K) { set_error("ntt: prime index out of range"); return 1; }
+    mid = index;
+  } else if (kind == 1) {
+    if (c->scheme != ABC_HIP_SCHEME_BFV || index < 0 || index >= c->nBsk) { set_error("ntt: Bsk index out of range"); return 1; }
+    mid = c->dc.id_bsk + index;
+  } else if (kind == 2) {
+    if (c->scheme != ABC_HIP_SCHEME_BFV) { set_error("ntt: no plaintext modulus in a CKKS context"); return 1; }
+    mid = c->dc.id_t;
+  } else {
+    set_error("ntt: bad modulus kind");
+    return 1;
+  }
+  LimbMap map{};
+  map.id[0] = mid;
+  return fwd ? launch_ntt_fwd(c, d, map, 1, count) : launch_ntt_inv(c, d, map, 1, count);
+}
+int abc_hip_ntt_forward(abc_hip_ctx *c, uint64_t *d, int kind, int index, size_t count) { CTX_GUARD(c); return ntt_entry(c, d, kind, index, count, true); }
+int abc_hip_ntt_inverse(abc_hip_ctx *c, uint64_t *d, int kind, int index, size_t count) { CTX_GUARD(c); return ntt_entry(c, d, kind, index, count, false); }
+
+int abc_hip_keyswitch(abc_hip_ctx *c, const uint64_t *target, uint32_t key_kind, uint64_t *out2, int nl, size_t count) {
+  CTX_GUARD(c);
+  if (check_level(c, nl)) return 1;
+  const uint64_t *key = nullptr;
+  if (key_kind == 0) key = c->d_relin;
+  else if (c->d_galois.count(key_kind)) key = c->d_galois[key_kind];
+  if (!key) { set_error("keyswitch: key not present"); return 1; }
+  return keyswitch_generic(c, target, (size_t)nl * c->n, key, out2, nl, count, nullptr, 0, false);
+}
+
+int abc_hip_microbench(abc_hip_ctx *c, int which, int iters, double *ms) { CTX_GUARD(c); return microbench(c, which, iters, ms); }
+
+int abc_hip_timer_start(abc_hip_ctx *c) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+  return 0;
+}
+int abc_hip_timer_stop(abc_hip_ctx *c, float *ms) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+  ABC_HIP_CHECK(hipEventSynchronize(c->ev1));
+  ABC_HIP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+
+}  // extern "C"

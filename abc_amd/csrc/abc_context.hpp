@@ -1,0 +1,145 @@
+// abc_context.hpp -- host-side context of libabc_hip.so and the structs shared with device code.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "abc_modarith.hpp"
+#include "abc_ntt.hpp"
+
+namespace abc {
+
+constexpr int kMaxLimbs = 16;
+
+// limb index -> modulus id (index into DevCtx::mods / twiddle tables)
+struct LimbMap {
+  int id[kMaxLimbs + 1];
+};
+
+// small read-only constants, one instance per context in device memory
+struct DevConst {
+  // key switching / modulus switching
+  u64 inv_special[kMaxLimbs], inv_special_s[kMaxLimbs];        // q_special^-1 mod q_j (+Shoup)
+  u64 inv_qlast[kMaxLimbs][kMaxLimbs], inv_qlast_s[kMaxLimbs][kMaxLimbs];  // [l][j] = q_l^-1 mod q_j
+  u64 special_mod_q[kMaxLimbs];                                // q_special mod q_j (key generation)
+  // BFV plaintext scaling (Evaluator::add_plain / Encryptor)
+  u64 q_mod_t, upper_half_threshold, t;
+  u64 coeff_div_plain[kMaxLimbs], upper_half_increment[kMaxLimbs];
+  // BEHZ
+  int nq, nB, nBsk, pad_;
+  u64 mtilde_mod_q[kMaxLimbs];
+  u64 inv_punct_q[kMaxLimbs];
+  u64 q_to_bsk[kMaxLimbs][kMaxLimbs];  // [j][i] (q/q_i) mod Bsk_j
+  u64 q_to_mtilde[kMaxLimbs];          // (q/q_i) mod 2^32
+  u64 neg_inv_q_mod_mtilde;
+  u64 q_mod_bsk[kMaxLimbs], inv_mtilde_mod_bsk[kMaxLimbs], inv_q_mod_bsk[kMaxLimbs];
+  u64 inv_punct_B[kMaxLimbs];
+  u64 B_to_q[kMaxLimbs][kMaxLimbs];  // [i][b] (B/B_b) mod q_i
+  u64 B_to_msk[kMaxLimbs];
+  u64 inv_B_mod_msk, B_mod_q[kMaxLimbs];
+  u64 t_mod_q[kMaxLimbs], t_mod_bsk[kMaxLimbs];
+  // BFV decryption (decrypt_scale_and_round)
+  u64 tgamma_mod_q[kMaxLimbs], q_to_t[kMaxLimbs], q_to_gamma[kMaxLimbs];
+  u64 neg_inv_q_mod_t, neg_inv_q_mod_gamma, inv_gamma_mod_t, gamma;
+};
+
+// passed BY VALUE to every kernel
+struct DevCtx {
+  const Mod *mods;      // [nmods]
+  const u64 *tw;        // [nmods][4][N]: tw, tws, itw, itws
+  const DevConst *cst;  //
+  const u32 *slot_map;  // [N] BatchEncoder index map (BFV)
+  int logn, n;
+  int K, L;             // key-level primes, data limbs
+  int id_bsk, id_t, id_gamma, id_mtilde;  // modulus ids: key primes are 0..K-1
+};
+
+__device__ __forceinline__ NttTable ntt_table(const DevCtx &c, int mid) {
+  const u64 *b = c.tw + (size_t)mid * 4 * c.n;
+  NttTable t;
+  t.tw = b; t.tws = b + c.n; t.itw = b + 2 * (size_t)c.n; t.itws = b + 3 * (size_t)c.n;
+  return t;
+}
+
+}  // namespace abc
+
+// The opaque C-ABI handle.
+struct abc_hip_ctx {
+  int scheme = 0, logn = 0, n = 0, K = 0, L = 0, device = 0;
+  std::vector<uint64_t> primes;  // key-level chain: data limbs + special
+  uint64_t t = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // moduli: ids 0..K-1 key primes, then Bsk (B_0..B_{nB-1}, m_sk), gamma, t, m_tilde(arith only)
+  std::vector<abc::Mod> h_mods;
+  std::vector<uint64_t> mod_values;
+  int nB = 0, nBsk = 0;
+  abc::DevCtx dc{};
+  abc::DevConst h_cst{};
+  abc::Mod *d_mods = nullptr;
+  uint64_t *d_tw = nullptr;
+  abc::DevConst *d_cst = nullptr;
+  uint32_t *d_slot_map = nullptr;
+  // keys (device)
+  uint64_t *d_sk = nullptr, *d_pk = nullptr, *d_relin = nullptr;
+  std::map<uint32_t, uint64_t *> d_galois;
+  std::vector<uint32_t> galois_order;
+  // workspace
+  void *ws = nullptr;
+  size_t ws_bytes = 0;
+  size_t limb_words() const { return (size_t)n; }
+  size_t key_words() const { return (size_t)L * 2 * K * n; }
+};
+
+namespace abc {
+
+void set_error(const std::string &msg);
+#define ABC_HIP_CHECK(expr)                                                                         \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      abc::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+      return 1;                                                                                     \
+    }                                                                                               \
+  } while (0)
+
+// workspace: grows on demand (never inside a timed region after warm-up)
+int ensure_workspace(abc_hip_ctx *c, size_t bytes);
+
+// ---- launchers implemented in the kernel translation units ----
+LimbMap key_limb_map(const abc_hip_ctx *c, int nl);  // 0..nl-1 -> data primes, nl -> special prime
+// in-place forward / inverse NTT over `limbs` consecutive limbs laid out [groups][nl][N]; limb j of each
+// group uses modulus map.id[j % nl]
+int launch_ntt_fwd(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
+int launch_ntt_inv(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
+
+int launch_addsub(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t polys, int op);  // 0 add 1 sub 2 neg
+int launch_ckks_tensor(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, int nl, size_t count);
+int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out2, int nl,
+                      size_t count, const u64 *addend, size_t addend_stride, bool add_c1);
+int launch_ks_tmod(abc_hip_ctx *c, const u64 *prodS, u64 *tmod, int nl, size_t polys);
+int launch_ks_finish(abc_hip_ctx *c, const u64 *prodD, const u64 *tmod, u64 *out, const u64 *addend, size_t addend_stride,
+                     bool add_c1, int nl, size_t count);
+int launch_galois(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, size_t polys, uint32_t elt, bool ntt_form);
+int launch_rescale(abc_hip_ctx *c, const u64 *in, u64 *out, int size, int nl, size_t count);
+int launch_drop_last(abc_hip_ctx *c, const u64 *in, u64 *out, int size, int nl, size_t count);
+
+int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t count);
+int bfv_multiply_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out, int size, size_t count);
+int bfv_addsub_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out, int size, size_t count, int sub);
+int ckks_multiply_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out, int size, int nl, size_t count);
+int ckks_add_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out, int size, int nl, size_t count, int sub);
+int batch_encode(abc_hip_ctx *c, const int64_t *values, u64 *plain, size_t count);
+int batch_decode(abc_hip_ctx *c, const u64 *plain, int64_t *values, size_t count);
+int encrypt(abc_hip_ctx *c, const u64 *plain, uint64_t seed, u64 *ct, size_t count);
+int decrypt(abc_hip_ctx *c, const u64 *ct, int size, int nl, u64 *plain, size_t count);
+int keygen(abc_hip_ctx *c, uint64_t seed);
+int microbench(abc_hip_ctx *c, int which, int iters, double *ms);
+
+// fused CKKS mul+relin fast path (N <= 2^14); returns -1 if not applicable
+int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count);
+
+}  // namespace abc

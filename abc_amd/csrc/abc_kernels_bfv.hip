@@ -1,0 +1,326 @@
+// abc_kernels_bfv.hip -- BFV-specific kernels: BEHZ RNS multiplication, plaintext operations,
+// BatchEncoder on the device, BFV decryption rounding.
+//
+// Reference call sites replaced:
+//   src/runtime/SealCiphertext.cpp:104,:122        Evaluator::multiply(_inplace)   -> bfv_multiply
+//   src/runtime/SealCiphertext.cpp:159,:196        Evaluator::multiply_plain       -> bfv_multiply_plain
+//   src/runtime/SealCiphertext.cpp:134,:145,:175,:184  add_plain / sub_plain       -> bfv_addsub_plain
+//   src/runtime/SealCiphertextFactory.cpp:130      BatchEncoder::encode            -> batch_encode
+//   src/runtime/SealCiphertextFactory.cpp:151      BatchEncoder::decode            -> batch_decode
+//   src/runtime/SealCiphertextFactory.cpp:150      Decryptor::decrypt (rounding)   -> k_bfv_decrypt_round
+// BEHZ (Bajard-Eynard-Hasan-Zucca) full-RNS multiply as SEAL implements it: extend q -> Bsk u {m~}
+// with a fast base conversion, Montgomery-reduce the q-overflow, tensor in both bases, scale by t,
+// fast floor by q into Bsk, Shenoy-Kumaresan conversion back to q.  These are element-wise over
+// coefficients (one lane = one coefficient, all limbs in registers), so they are HBM-streaming kernels.
+#include "abc_context.hpp"
+
+namespace abc {
+
+static inline unsigned grid_for(size_t items, int block) {
+  size_t g = (items + block - 1) / block;
+  const size_t cap = 256 * 8 * 4;
+  return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+
+// sum_i a[i]*b[i] mod m with a[i] < 2^61, b[i] < m.q: flush the 128-bit accumulator every 4 terms
+// (barrett_reduce precondition x < 2^(k+63)).
+template <class FA, class FB>
+__device__ __forceinline__ u64 dot_mod(int n, FA a, FB b, const Mod &m) {
+  u64 res = 0;
+  for (int i0 = 0; i0 < n; i0 += 4) {
+    U128 acc{0, 0};
+    const int i1 = (i0 + 4 < n) ? i0 + 4 : n;
+    for (int i = i0; i < i1; i++) mac128(acc, a(i), b(i));
+    res = add_mod(res, barrett_reduce(acc, m), m.q);
+  }
+  return res;
+}
+
+// ---- BEHZ steps (1)-(2): q -> Bsk with Montgomery reduction of the q-overflow ----
+// in: [polys][L][N] coefficient form; out: [polys][nBsk][N]
+__global__ __launch_bounds__(256) void k_behz_extend(DevCtx c, const u64 *in, u64 *out, size_t polys) {
+  const DevConst &k = *c.cst;
+  const int L = k.nq, nBsk = k.nBsk;
+  const size_t items = polys * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, x = it & (c.n - 1);
+    u64 tmp[kMaxLimbs];
+    u32 mt = 0;
+    for (int i = 0; i < L; i++) {
+      const Mod m = c.mods[i];
+      u64 v = mul_mod(in[(p * L + i) * c.n + x], k.mtilde_mod_q[i], m);  // * m~
+      v = mul_mod(v, k.inv_punct_q[i], m);                               // * (q/q_i)^-1
+      tmp[i] = v;
+      mt += (u32)v * (u32)k.q_to_mtilde[i];  // arithmetic mod 2^32
+    }
+    const u32 r32 = mt * (u32)k.neg_inv_q_mod_mtilde;
+    for (int j = 0; j < nBsk; j++) {
+      const Mod m = c.mods[c.id_bsk + j];
+      const u64 conv = dot_mod(L, [&](int i) { return tmp[i]; }, [&](int i) { return k.q_to_bsk[j][i]; }, m);
+      u64 r = r32;
+      if (r32 >= 0x80000000u) r += m.q - 0x100000000ull;  // centred representative of r mod m~
+      U128 acc = mul_wide(r, k.q_mod_bsk[j]);
+      add128(acc, U128{conv, 0});
+      const u64 v = barrett_reduce(acc, m);
+      out[(p * nBsk + j) * c.n + x] = mul_mod(v, k.inv_mtilde_mod_bsk[j], m);
+    }
+  }
+}
+
+// ---- dyadic tensor over an arbitrary limb set: a,b [count][2][nlm][N] -> d [count][3][nlm][N] ----
+__global__ __launch_bounds__(256) void k_tensor_map(DevCtx c, const u64 *a, const u64 *b, u64 *d, LimbMap map, int nlm,
+                                                    size_t count) {
+  const size_t pw = (size_t)nlm * c.n;
+  const size_t items = count * pw;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t ct = it / pw, w = it % pw;
+    const Mod m = c.mods[map.id[w >> c.logn]];
+    const u64 *pa = a + ct * 2 * pw + w, *pb = b + ct * 2 * pw + w;
+    const u64 a0 = pa[0], a1 = pa[pw], b0 = pb[0], b1 = pb[pw];
+    u64 *po = d + ct * 3 * pw + w;
+    po[0] = mul_mod(a0, b0, m);
+    po[pw] = add_mod(mul_mod(a0, b1, m), mul_mod(a1, b0, m), m.q);
+    po[2 * pw] = mul_mod(a1, b1, m);
+  }
+}
+
+// ---- BEHZ steps (6)-(8): scale by t, fast floor by q, Shenoy-Kumaresan back to q ----
+// dq [polys][L][N], dB [polys][nBsk][N] (coefficient form) -> out [polys][L][N]
+__global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, const u64 *dB, u64 *out, size_t polys) {
+  const DevConst &k = *c.cst;
+  const int L = k.nq, nB = k.nB, nBsk = k.nBsk;
+  const size_t items = polys * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const Mod msk = c.mods[c.id_bsk + nB];
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, x = it & (c.n - 1);
+    u64 tq[kMaxLimbs], fl[kMaxLimbs];
+    for (int i = 0; i < L; i++) {
+      const Mod m = c.mods[i];
+      u64 v = mul_mod(dq[(p * L + i) * c.n + x], k.t_mod_q[i], m);
+      tq[i] = mul_mod(v, k.inv_punct_q[i], m);
+    }
+    for (int j = 0; j < nBsk; j++) {
+      const Mod m = c.mods[c.id_bsk + j];
+      const u64 conv = dot_mod(L, [&](int i) { return tq[i]; }, [&](int i) { return k.q_to_bsk[j][i]; }, m);
+      const u64 xb = mul_mod(dB[(p * nBsk + j) * c.n + x], k.t_mod_bsk[j], m);
+      fl[j] = mul_mod(sub_mod(xb, conv, m.q), k.inv_q_mod_bsk[j], m);
+    }
+    u64 tb[kMaxLimbs];
+    for (int b2 = 0; b2 < nB; b2++) tb[b2] = mul_mod(fl[b2], k.inv_punct_B[b2], c.mods[c.id_bsk + b2]);
+    const u64 msk_conv = dot_mod(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_msk[b2]; }, msk);
+    const u64 alpha = mul_mod(sub_mod(msk_conv, fl[nB], msk.q), k.inv_B_mod_msk, msk);
+    const bool neg = alpha > (msk.q >> 1);
+    for (int i = 0; i < L; i++) {
+      const Mod m = c.mods[i];
+      u64 v = dot_mod(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_q[i][b2]; }, m);
+      if (neg) v = add_mod(v, mul_mod(msk.q - alpha, k.B_mod_q[i], m), m.q);
+      else v = sub_mod(v, mul_mod(alpha, k.B_mod_q[i], m), m.q);
+      out[(p * L + i) * c.n + x] = v;
+    }
+  }
+}
+
+int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t count) {
+  if (c->scheme != 1) { set_error("bfv_multiply on a non-BFV context"); return 1; }
+  if (!count) return 0;
+  const size_t N = (size_t)c->n;
+  const int L = c->L, nBsk = c->nBsk, nlm = L + nBsk;
+  // per ciphertext pair (words): aq,bq 2*2L ; aB,bB 2*2nBsk ; dq 3L ; dB 3nBsk
+  const size_t per_ct = (size_t)(4 * L + 4 * nBsk + 3 * L + 3 * nBsk) * N;
+  size_t chunk = (((size_t)1 << 30) / 8) / per_ct;
+  if (chunk < 1) chunk = 1;
+  if (chunk > count) chunk = count;
+  if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
+  u64 *aq = (u64 *)c->ws, *bq = aq + chunk * 2 * L * N;
+  u64 *aB = bq + chunk * 2 * L * N, *bB = aB + chunk * 2 * nBsk * N;
+  u64 *dq = bB + chunk * 2 * nBsk * N, *dB = dq + chunk * 3 * L * N;
+  const LimbMap qmap = key_limb_map(c, L);
+  LimbMap bmap{};
+  for (int j = 0; j < nBsk; j++) bmap.id[j] = c->dc.id_bsk + j;
+  (void)nlm;
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t cc = (count - off < chunk) ? count - off : chunk;
+    const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
+    const size_t in_bytes = cc * 2 * L * N * 8;
+    ABC_HIP_CHECK(hipMemcpyAsync(aq, pa, in_bytes, hipMemcpyDeviceToDevice, c->stream));
+    ABC_HIP_CHECK(hipMemcpyAsync(bq, pb, in_bytes, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_behz_extend, dim3(grid_for(cc * 2 * N, 256)), dim3(256), 0, c->stream, c->dc, pa, aB, cc * 2);
+    hipLaunchKernelGGL(k_behz_extend, dim3(grid_for(cc * 2 * N, 256)), dim3(256), 0, c->stream, c->dc, pb, bB, cc * 2);
+    ABC_HIP_CHECK(hipGetLastError());
+    if (launch_ntt_fwd(c, aq, qmap, L, cc * 4 * L)) return 1;          // aq and bq are adjacent
+    if (launch_ntt_fwd(c, aB, bmap, nBsk, cc * 4 * nBsk)) return 1;    // aB and bB are adjacent
+    hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * L * N, 256)), dim3(256), 0, c->stream, c->dc, aq, bq, dq, qmap, L, cc);
+    hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * nBsk * N, 256)), dim3(256), 0, c->stream, c->dc, aB, bB, dB, bmap, nBsk,
+                       cc);
+    ABC_HIP_CHECK(hipGetLastError());
+    if (launch_ntt_inv(c, dq, qmap, L, cc * 3 * L)) return 1;
+    if (launch_ntt_inv(c, dB, bmap, nBsk, cc * 3 * nBsk)) return 1;
+    hipLaunchKernelGGL(k_behz_floor, dim3(grid_for(cc * 3 * N, 256)), dim3(256), 0, c->stream, c->dc, dq, dB,
+                       out3 + off * 3 * L * N, cc * 3);
+    ABC_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+// ---- multiply_plain: lift plaintext to each q_i, NTT, dyadic multiply, INTT ----
+__global__ __launch_bounds__(256) void k_plain_lift(DevCtx c, const u64 *plain, u64 *lifted, size_t count) {
+  const DevConst &k = *c.cst;
+  const size_t items = count * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, x = it & (c.n - 1);
+    const u64 v = plain[it];
+    const bool upper = v >= k.upper_half_threshold;
+    for (int i = 0; i < c.L; i++) lifted[(p * c.L + i) * c.n + x] = v + (upper ? k.upper_half_increment[i] : 0);
+  }
+}
+__global__ __launch_bounds__(256) void k_mul_plain_ntt(DevCtx c, u64 *ct, const u64 *lifted, size_t lifted_stride, int size,
+                                                       size_t count) {
+  const size_t pw = (size_t)c.L * c.n;
+  const size_t items = count * size * pw;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t ctp = it / pw, w = it % pw;
+    const size_t ci = ctp / size;
+    ct[it] = mul_mod(ct[it], lifted[ci * lifted_stride + w], c.mods[w >> c.logn]);
+  }
+}
+
+int bfv_multiply_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out, int size, size_t count) {
+  if (!count) return 0;
+  const size_t N = (size_t)c->n;
+  const int L = c->L;
+  const size_t nplain = plain_stride ? count : 1;
+  if (ensure_workspace(c, nplain * L * N * 8)) return 1;
+  u64 *lifted = (u64 *)c->ws;
+  const LimbMap qmap = key_limb_map(c, L);
+  if (plain_stride && plain_stride != N) { set_error("multiply_plain: plain_stride must be 0 or N"); return 1; }
+  hipLaunchKernelGGL(k_plain_lift, dim3(grid_for(nplain * N, 256)), dim3(256), 0, c->stream, c->dc, plain, lifted, nplain);
+  ABC_HIP_CHECK(hipGetLastError());
+  if (launch_ntt_fwd(c, lifted, qmap, L, nplain * L)) return 1;
+  if (out != ct) ABC_HIP_CHECK(hipMemcpyAsync(out, ct, count * size * L * N * 8, hipMemcpyDeviceToDevice, c->stream));
+  if (launch_ntt_fwd(c, out, qmap, L, count * size * L)) return 1;
+  hipLaunchKernelGGL(k_mul_plain_ntt, dim3(grid_for(count * size * L * N, 256)), dim3(256), 0, c->stream, c->dc, out, lifted,
+                     plain_stride ? (size_t)L * N : 0, size, count);
+  ABC_HIP_CHECK(hipGetLastError());
+  return launch_ntt_inv(c, out, qmap, L, count * size * L);
+}
+
+// ---- add_plain / sub_plain: c0 +/- round(q*m/t)  (multiply_add_plain_with_scaling_variant) ----
+__global__ __launch_bounds__(256) void k_plain_scale_addsub(DevCtx c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out,
+                                                            int size, size_t count, int sub) {
+  const DevConst &k = *c.cst;
+  const Mod mt = c.mods[c.id_t];
+  const size_t items = count * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t pw = (size_t)c.L * c.n;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t ci = it >> c.logn, x = it & (c.n - 1);
+    const u64 m = plain[ci * plain_stride + x];
+    // fix = floor((m * (q mod t) + (t+1)/2) / t); numerator < t^2 + t < 2^41
+    const u64 numer = m * k.q_mod_t + k.upper_half_threshold;
+    const u64 rem = reduce64(numer, mt);
+    const u64 fix = (numer - rem) / mt.q;  // exact division of a < 2^41 value
+    for (int i = 0; i < c.L; i++) {
+      const Mod mq = c.mods[i];
+      const u64 scaled = add_mod(mul_mod(m, k.coeff_div_plain[i], mq), fix, mq.q);
+      const size_t o = ci * size * pw + (size_t)i * c.n + x;
+      out[o] = sub ? sub_mod(ct[o], scaled, mq.q) : add_mod(ct[o], scaled, mq.q);
+    }
+  }
+}
+
+int bfv_addsub_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out, int size, size_t count,
+                     int sub) {
+  if (!count) return 0;
+  const size_t N = (size_t)c->n;
+  if (out != ct) ABC_HIP_CHECK(hipMemcpyAsync(out, ct, count * size * c->L * N * 8, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_plain_scale_addsub, dim3(grid_for(count * N, 256)), dim3(256), 0, c->stream, c->dc, out, plain,
+                     plain_stride, out, size, count, sub);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- BatchEncoder ----
+__global__ __launch_bounds__(256) void k_batch_scatter(DevCtx c, const int64_t *values, u64 *plain, size_t count) {
+  const u64 t = c.cst->t;
+  const size_t items = count * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, i = it & (c.n - 1);
+    const int64_t v = values[it];
+    plain[p * c.n + c.slot_map[i]] = v < 0 ? t + (u64)v : (u64)v;
+  }
+}
+__global__ __launch_bounds__(256) void k_batch_gather(DevCtx c, const u64 *tmp, int64_t *values, size_t count) {
+  const u64 t = c.cst->t, half = t >> 1;
+  const size_t items = count * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, i = it & (c.n - 1);
+    const u64 v = tmp[p * c.n + c.slot_map[i]];
+    values[it] = v > half ? (int64_t)v - (int64_t)t : (int64_t)v;
+  }
+}
+
+int batch_encode(abc_hip_ctx *c, const int64_t *values, u64 *plain, size_t count) {
+  if (c->scheme != 1) { set_error("batch_encode needs a BFV context"); return 1; }
+  if (!count) return 0;
+  hipLaunchKernelGGL(k_batch_scatter, dim3(grid_for(count * c->n, 256)), dim3(256), 0, c->stream, c->dc, values, plain, count);
+  ABC_HIP_CHECK(hipGetLastError());
+  LimbMap tmap{};
+  tmap.id[0] = c->dc.id_t;
+  return launch_ntt_inv(c, plain, tmap, 1, count);
+}
+
+int batch_decode(abc_hip_ctx *c, const u64 *plain, int64_t *values, size_t count) {
+  if (c->scheme != 1) { set_error("batch_decode needs a BFV context"); return 1; }
+  if (!count) return 0;
+  const size_t N = (size_t)c->n;
+  if (ensure_workspace(c, count * N * 8)) return 1;
+  u64 *tmp = (u64 *)c->ws;
+  ABC_HIP_CHECK(hipMemcpyAsync(tmp, plain, count * N * 8, hipMemcpyDeviceToDevice, c->stream));
+  LimbMap tmap{};
+  tmap.id[0] = c->dc.id_t;
+  if (launch_ntt_fwd(c, tmp, tmap, 1, count)) return 1;
+  hipLaunchKernelGGL(k_batch_gather, dim3(grid_for(count * N, 256)), dim3(256), 0, c->stream, c->dc, tmp, values, count);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- BFV decryption rounding: phase [count][L][N] (coefficient form) -> plain [count][N] ----
+__global__ __launch_bounds__(256) void k_bfv_decrypt_round(DevCtx c, const u64 *phase, u64 *plain, size_t count) {
+  const DevConst &k = *c.cst;
+  const Mod mt = c.mods[c.id_t], mg = c.mods[c.id_gamma];
+  const size_t items = count * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, x = it & (c.n - 1);
+    u64 tmp[kMaxLimbs];
+    for (int i = 0; i < c.L; i++) {
+      const Mod m = c.mods[i];
+      const u64 v = mul_mod(phase[(p * c.L + i) * c.n + x], k.tgamma_mod_q[i], m);
+      tmp[i] = mul_mod(v, k.inv_punct_q[i], m);
+    }
+    u64 vt = dot_mod(c.L, [&](int i) { return tmp[i]; }, [&](int i) { return k.q_to_t[i]; }, mt);
+    u64 vg = dot_mod(c.L, [&](int i) { return tmp[i]; }, [&](int i) { return k.q_to_gamma[i]; }, mg);
+    vt = mul_mod(vt, k.neg_inv_q_mod_t, mt);
+    vg = mul_mod(vg, k.neg_inv_q_mod_gamma, mg);
+    u64 r;
+    if (vg > (mg.q >> 1)) r = add_mod(vt, reduce64(mg.q - vg, mt), mt.q);
+    else r = sub_mod(vt, reduce64(vg, mt), mt.q);
+    if (r) r = mul_mod(r, k.inv_gamma_mod_t, mt);
+    plain[it] = r;
+  }
+}
+
+int launch_bfv_decrypt_round(abc_hip_ctx *c, const u64 *phase, u64 *plain, size_t count) {
+  hipLaunchKernelGGL(k_bfv_decrypt_round, dim3(grid_for(count * c->n, 256)), dim3(256), 0, c->stream, c->dc, phase, plain, count);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace abc

@@ -1,0 +1,367 @@
+// abc_kernels_eval.hip -- evaluator kernels shared by BFV and CKKS (generic, any N = 2^10..2^16):
+// limb-wise add/sub/negate, CKKS dyadic tensor, hybrid key switching with one special prime,
+// Galois automorphisms, rescale / modulus drop.
+//
+// Reference call sites replaced (src/runtime/SealCiphertext.cpp): add :92,:114; sub :98,:118;
+// negate :157,:193; relinearize_inplace :105,:123,:160,:197; rotate_rows :55,:60.
+// Key switching follows seal::Evaluator::switch_key_inplace: decomposition limb J is reduced modulo
+// every key-level prime, transformed, multiplied with key[J] and accumulated; the special-prime limb is
+// then divided out with rounding.  All outputs are fully reduced, hence bit-comparable with oracle/.
+#include "abc_context.hpp"
+
+namespace abc {
+
+LimbMap key_limb_map(const abc_hip_ctx *c, int nl) {
+  LimbMap m{};
+  for (int j = 0; j < nl; j++) m.id[j] = j;
+  m.id[nl] = c->K - 1;
+  return m;
+}
+
+static inline unsigned grid_for(size_t items, int block) {
+  size_t g = (items + block - 1) / block;
+  const size_t cap = 256 * 8 * 4;  // enough workgroups to fill 256 CUs several times, grid-stride beyond
+  return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+
+// ---- limb-wise add / sub / negate:  data viewed as [polys][nl][N] ----
+__global__ __launch_bounds__(256) void k_addsub(DevCtx c, const u64 *a, const u64 *b, u64 *out, int nl, size_t words, int op) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
+  for (size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; w < words; w += stride) {
+    const int j = (int)((w >> c.logn) % nl);
+    const u64 q = c.mods[j].q;
+    u64x2 x = *reinterpret_cast<const u64x2 *>(a + w);
+    u64x2 r;
+    if (op == 2) {
+      r.x = neg_mod(x.x, q);
+      r.y = neg_mod(x.y, q);
+    } else {
+      u64x2 y = *reinterpret_cast<const u64x2 *>(b + w);
+      if (op == 0) { r.x = add_mod(x.x, y.x, q); r.y = add_mod(x.y, y.y, q); }
+      else { r.x = sub_mod(x.x, y.x, q); r.y = sub_mod(x.y, y.y, q); }
+    }
+    *reinterpret_cast<u64x2 *>(out + w) = r;
+  }
+}
+
+int launch_addsub(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t polys, int op) {
+  const size_t words = polys * nl * (size_t)c->n;
+  if (!words) return 0;
+  hipLaunchKernelGGL(k_addsub, dim3(grid_for(words / 2, 256)), dim3(256), 0, c->stream, c->dc, a, b, out, nl, words, op);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- CKKS tensor product: (a0,a1) x (b0,b1) -> (a0b0, a0b1+a1b0, a1b1), NTT form ----
+__global__ __launch_bounds__(256) void k_ckks_tensor(DevCtx c, const u64 *a, const u64 *b, u64 *out3, int nl, size_t count) {
+  const size_t pw = (size_t)nl * c.n;  // words per polynomial
+  const size_t items = count * pw;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t ct = it / pw, w = it % pw;
+    const Mod m = c.mods[w >> c.logn];
+    const u64 *pa = a + ct * 2 * pw + w, *pb = b + ct * 2 * pw + w;
+    const u64 a0 = pa[0], a1 = pa[pw], b0 = pb[0], b1 = pb[pw];
+    u64 *po = out3 + ct * 3 * pw + w;
+    po[0] = mul_mod(a0, b0, m);
+    U128 acc = mul_wide(a0, b1);
+    mac128(acc, a1, b0);
+    po[pw] = barrett_reduce(acc, m);
+    po[2 * pw] = mul_mod(a1, b1, m);
+  }
+}
+
+int launch_ckks_tensor(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, int nl, size_t count) {
+  const size_t items = count * nl * (size_t)c->n;
+  if (!items) return 0;
+  hipLaunchKernelGGL(k_ckks_tensor, dim3(grid_for(items, 256)), dim3(256), 0, c->stream, c->dc, a, b, out3, nl, count);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- key switching, generic path ----
+// dec[ct][J][I][k] = tcoef[ct][J][k] mod q_{ki(I)}
+__global__ __launch_bounds__(256) void k_ks_expand(DevCtx c, const u64 *tcoef, size_t tstride, u64 *dec, int nl, size_t count) {
+  const size_t per_ct = (size_t)nl * c.n;
+  const size_t items = count * per_ct;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t ct = it / per_ct, r = it % per_ct;
+    const int J = (int)(r >> c.logn);
+    const size_t k = r & (c.n - 1);
+    const u64 v = tcoef[ct * tstride + r];
+    u64 *d = dec + ((ct * nl + J) * (size_t)(nl + 1)) * c.n + k;
+    for (int I = 0; I <= nl; I++) {
+      const int ki = (I == nl) ? c.K - 1 : I;
+      d[(size_t)I * c.n] = reduce64(v, c.mods[ki]);
+    }
+  }
+}
+
+// prodD[ct][comp][I<nl][k], prodS[ct][comp][k] = sum_J dec[ct][J][I][k] * key[J][comp][ki][k]
+__global__ __launch_bounds__(256) void k_ks_inner(DevCtx c, const u64 *dec, const u64 *key, u64 *prodD, u64 *prodS, int nl,
+                                                  size_t count) {
+  const size_t per_ct = (size_t)(nl + 1) * c.n;
+  const size_t items = count * per_ct;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t ct = it / per_ct, r = it % per_ct;
+    const int I = (int)(r >> c.logn);
+    const size_t k = r & (c.n - 1);
+    const int ki = (I == nl) ? c.K - 1 : I;
+    const Mod m = c.mods[ki];
+    u64 acc0 = 0, acc1 = 0;
+    for (int J = 0; J < nl; J++) {
+      const u64 x = dec[((ct * nl + J) * (size_t)(nl + 1) + I) * c.n + k];
+      const u64 *kj = key + (((size_t)J * 2) * c.K + ki) * c.n + k;
+      acc0 = add_mod(acc0, mul_mod(x, kj[0], m), m.q);
+      acc1 = add_mod(acc1, mul_mod(x, kj[(size_t)c.K * c.n], m), m.q);
+    }
+    if (I == nl) {
+      prodS[(ct * 2 + 0) * c.n + k] = acc0;
+      prodS[(ct * 2 + 1) * c.n + k] = acc1;
+    } else {
+      prodD[((ct * 2 + 0) * nl + I) * c.n + k] = acc0;
+      prodD[((ct * 2 + 1) * nl + I) * c.n + k] = acc1;
+    }
+  }
+}
+
+// tmod[ct][comp][j][k] = ((prodS + half) mod q_sp) mod q_j  + (q_j - half mod q_j)
+__global__ __launch_bounds__(256) void k_ks_tmod(DevCtx c, const u64 *prodS, u64 *tmod, int nl, size_t polys) {
+  const size_t items = polys * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const Mod msp = c.mods[c.K - 1];
+  const u64 half = msp.q >> 1;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, k = it & (c.n - 1);
+    const u64 last = add_mod(prodS[it], half, msp.q);
+    for (int j = 0; j < nl; j++) {
+      const Mod m = c.mods[j];
+      const u64 fix = m.q - reduce64(half, m);
+      tmod[(p * nl + j) * c.n + k] = add_mod(reduce64(last, m), fix == m.q ? 0 : fix, m.q);
+    }
+  }
+}
+
+// out[ct][comp][j][k] = (prodD - tmod) * q_sp^-1 mod q_j  (+ addend)
+__global__ __launch_bounds__(256) void k_ks_finish(DevCtx c, const u64 *prodD, const u64 *tmod, u64 *out, const u64 *addend,
+                                                   size_t addend_stride, int add_c1, int nl, size_t count) {
+  const size_t pw = (size_t)nl * c.n;
+  const size_t items = count * 2 * pw;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t ct = it / (2 * pw), r = it % (2 * pw);
+    const int comp = (int)(r / pw);
+    const size_t w = r % pw;
+    const int j = (int)(w >> c.logn);
+    const u64 q = c.mods[j].q;
+    u64 v = mul_shoup(sub_mod(prodD[it], tmod[it], q), c.cst->inv_special[j], c.cst->inv_special_s[j], q);
+    if (addend && (comp == 0 || add_c1)) v = add_mod(v, addend[ct * addend_stride + r], q);
+    out[it] = v;
+  }
+}
+
+int launch_ks_tmod(abc_hip_ctx *c, const u64 *prodS, u64 *tmod, int nl, size_t polys) {
+  hipLaunchKernelGGL(k_ks_tmod, dim3(grid_for(polys * c->n, 256)), dim3(256), 0, c->stream, c->dc, prodS, tmod, nl, polys);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int launch_ks_finish(abc_hip_ctx *c, const u64 *prodD, const u64 *tmod, u64 *out, const u64 *addend, size_t addend_stride,
+                     bool add_c1, int nl, size_t count) {
+  hipLaunchKernelGGL(k_ks_finish, dim3(grid_for(count * 2 * nl * (size_t)c->n, 256)), dim3(256), 0, c->stream, c->dc, prodD, tmod,
+                     out, addend, addend_stride, add_c1 ? 1 : 0, nl, count);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out2, int nl, size_t count,
+                      const u64 *addend, size_t addend_stride, bool add_c1) {
+  if (!count) return 0;
+  const bool ckks = (c->scheme == 2);
+  const size_t N = (size_t)c->n;
+  // workspace per ciphertext (words): tcoef nl + dec nl(nl+1) + prodD 2nl + prodS 2 + tmod 2nl
+  const size_t per_ct = ((size_t)nl + (size_t)nl * (nl + 1) + 2 * nl + 2 + 2 * nl) * N;
+  const size_t budget_words = ((size_t)1 << 30) / 8;  // <= 1 GiB of scratch per chunk
+  size_t chunk = budget_words / per_ct;
+  if (chunk < 1) chunk = 1;
+  if (chunk > count) chunk = count;
+  if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
+  u64 *tcoef = (u64 *)c->ws;
+  u64 *dec = tcoef + chunk * nl * N;
+  u64 *prodD = dec + chunk * nl * (nl + 1) * N;
+  u64 *prodS = prodD + chunk * 2 * nl * N;
+  u64 *tmod = prodS + chunk * 2 * N;
+  const LimbMap dmap = key_limb_map(c, nl);
+  LimbMap smap{};
+  smap.id[0] = c->K - 1;
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t cc = (count - off < chunk) ? count - off : chunk;
+    const u64 *tg = target + off * target_stride;
+    const u64 *tc = tg;
+    size_t tcs = target_stride;
+    if (ckks) {  // CKKS targets are in NTT form: back to coefficients first
+      ABC_HIP_CHECK(hipMemcpy2DAsync(tcoef, nl * N * 8, tg, target_stride * 8, nl * N * 8, cc, hipMemcpyDeviceToDevice,
+                                     c->stream));
+      if (launch_ntt_inv(c, tcoef, dmap, nl, cc * nl)) return 1;
+      tc = tcoef;
+      tcs = nl * N;
+    }
+    hipLaunchKernelGGL(k_ks_expand, dim3(grid_for(cc * nl * N, 256)), dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl, cc);
+    ABC_HIP_CHECK(hipGetLastError());
+    if (launch_ntt_fwd(c, dec, dmap, nl + 1, cc * nl * (nl + 1))) return 1;
+    hipLaunchKernelGGL(k_ks_inner, dim3(grid_for(cc * (nl + 1) * N, 256)), dim3(256), 0, c->stream, c->dc, dec, key, prodD,
+                       prodS, nl, cc);
+    ABC_HIP_CHECK(hipGetLastError());
+    if (launch_ntt_inv(c, prodS, smap, 1, cc * 2)) return 1;
+    if (launch_ks_tmod(c, prodS, tmod, nl, cc * 2)) return 1;
+    if (ckks) {
+      if (launch_ntt_fwd(c, tmod, dmap, nl, cc * 2 * nl)) return 1;
+    } else {
+      if (launch_ntt_inv(c, prodD, dmap, nl, cc * 2 * nl)) return 1;
+    }
+    if (launch_ks_finish(c, prodD, tmod, out2 + off * 2 * nl * N, addend ? addend + off * addend_stride : nullptr, addend_stride,
+                         add_c1, nl, cc))
+      return 1;
+  }
+  return 0;
+}
+
+// ---- Galois automorphism x -> x^elt on [polys][nl][N] ----
+__global__ __launch_bounds__(256) void k_galois(DevCtx c, const u64 *in, u64 *out, int nl, size_t polys, u32 elt, int ntt_form) {
+  const size_t items = polys * nl * (size_t)c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t limb = it >> c.logn;
+    const u32 i = (u32)(it & (c.n - 1));
+    const u64 *src = in + limb * c.n;
+    u64 *dst = out + limb * c.n;
+    if (ntt_form) {
+      // slot i holds the evaluation at psi^(2*bitrev(i)+1); gather from the slot holding exponent*elt
+      const u32 rev = bitrev32(i + (u32)c.n, c.logn + 1);
+      const u64 idx = (((u64)elt * rev) >> 1) & (u64)(c.n - 1);
+      dst[i] = src[bitrev32((u32)idx, c.logn)];
+    } else {
+      const u64 raw = (u64)i * elt;
+      const u32 idx = (u32)(raw & (u64)(c.n - 1));
+      u64 v = src[i];
+      if ((raw >> c.logn) & 1) v = neg_mod(v, c.mods[limb % nl].q);
+      dst[idx] = v;
+    }
+  }
+}
+
+int launch_galois(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, size_t polys, uint32_t elt, bool ntt_form) {
+  const size_t items = polys * nl * (size_t)c->n;
+  if (!items) return 0;
+  hipLaunchKernelGGL(k_galois, dim3(grid_for(items, 256)), dim3(256), 0, c->stream, c->dc, in, out, nl, polys, elt,
+                     ntt_form ? 1 : 0);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- CKKS rescale: drop limb nl-1 with rounding (divide_and_round_q_last_ntt) ----
+__global__ __launch_bounds__(256) void k_gather_last(DevCtx c, const u64 *in, u64 *last, int nl, size_t polys) {
+  const size_t items = polys * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, k = it & (c.n - 1);
+    last[it] = in[(p * nl + (nl - 1)) * c.n + k];
+  }
+}
+__global__ __launch_bounds__(256) void k_rescale_tmod(DevCtx c, const u64 *last, u64 *tmod, int nl, size_t polys) {
+  const size_t items = polys * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const Mod ml = c.mods[nl - 1];
+  const u64 half = ml.q >> 1;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, k = it & (c.n - 1);
+    const u64 v = add_mod(last[it], half, ml.q);
+    for (int j = 0; j < nl - 1; j++) {
+      const Mod m = c.mods[j];
+      const u64 hm = reduce64(half, m);
+      tmod[(p * (nl - 1) + j) * c.n + k] = add_mod(reduce64(v, m), hm ? m.q - hm : 0, m.q);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_rescale_finish(DevCtx c, const u64 *in, const u64 *tmod, u64 *out, int nl, size_t polys) {
+  const int nlo = nl - 1;
+  const size_t items = polys * nlo * (size_t)c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t limb = it >> c.logn, k = it & (c.n - 1);
+    const size_t p = limb / nlo;
+    const int j = (int)(limb % nlo);
+    const u64 q = c.mods[j].q;
+    const u64 x = in[(p * nl + j) * c.n + k];
+    out[it] = mul_shoup(sub_mod(x, tmod[it], q), c.cst->inv_qlast[nl - 1][j], c.cst->inv_qlast_s[nl - 1][j], q);
+  }
+}
+
+int launch_rescale(abc_hip_ctx *c, const u64 *in, u64 *out, int size, int nl, size_t count) {
+  if (nl < 2) { set_error("rescale: no limb left to drop"); return 1; }
+  const size_t N = (size_t)c->n, polys = count * size;
+  if (!polys) return 0;
+  if (ensure_workspace(c, (polys * N + polys * (nl - 1) * N) * 8)) return 1;
+  u64 *last = (u64 *)c->ws, *tmod = last + polys * N;
+  hipLaunchKernelGGL(k_gather_last, dim3(grid_for(polys * N, 256)), dim3(256), 0, c->stream, c->dc, in, last, nl, polys);
+  ABC_HIP_CHECK(hipGetLastError());
+  LimbMap lmap{};
+  lmap.id[0] = nl - 1;
+  if (launch_ntt_inv(c, last, lmap, 1, polys)) return 1;
+  hipLaunchKernelGGL(k_rescale_tmod, dim3(grid_for(polys * N, 256)), dim3(256), 0, c->stream, c->dc, last, tmod, nl, polys);
+  ABC_HIP_CHECK(hipGetLastError());
+  if (launch_ntt_fwd(c, tmod, key_limb_map(c, nl - 1), nl - 1, polys * (nl - 1))) return 1;
+  hipLaunchKernelGGL(k_rescale_finish, dim3(grid_for(polys * (nl - 1) * N, 256)), dim3(256), 0, c->stream, c->dc, in, tmod, out,
+                     nl, polys);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+int launch_drop_last(abc_hip_ctx *c, const u64 *in, u64 *out, int size, int nl, size_t count) {
+  if (nl < 2) { set_error("mod_switch: no limb left to drop"); return 1; }
+  const size_t N = (size_t)c->n, polys = count * size;
+  if (!polys) return 0;
+  ABC_HIP_CHECK(hipMemcpy2DAsync(out, (nl - 1) * N * 8, in, nl * N * 8, (nl - 1) * N * 8, polys, hipMemcpyDeviceToDevice,
+                                 c->stream));
+  return 0;
+}
+
+// ---- CKKS plaintext ops (NTT-form plaintext [nl][N]) ----
+__global__ __launch_bounds__(256) void k_ckks_plain(DevCtx c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out,
+                                                    int size, int nl, size_t count, int op) {
+  const size_t pw = (size_t)nl * c.n;
+  const size_t items = count * size * pw;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t ctp = it / pw, w = it % pw;
+    const size_t ci = ctp / size;
+    const int p = (int)(ctp % size);
+    const Mod m = c.mods[w >> c.logn];
+    const u64 pv = plain[ci * plain_stride + w];
+    u64 v = ct[it];
+    if (op == 0) v = mul_mod(v, pv, m);
+    else if (p == 0) v = (op == 1) ? add_mod(v, pv, m.q) : sub_mod(v, pv, m.q);
+    out[it] = v;
+  }
+}
+int ckks_multiply_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out, int size, int nl,
+                        size_t count) {
+  const size_t items = count * size * nl * (size_t)c->n;
+  if (!items) return 0;
+  hipLaunchKernelGGL(k_ckks_plain, dim3(grid_for(items, 256)), dim3(256), 0, c->stream, c->dc, ct, plain, plain_stride, out, size,
+                     nl, count, 0);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+int ckks_add_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out, int size, int nl, size_t count,
+                   int sub) {
+  const size_t items = count * size * nl * (size_t)c->n;
+  if (!items) return 0;
+  hipLaunchKernelGGL(k_ckks_plain, dim3(grid_for(items, 256)), dim3(256), 0, c->stream, c->dc, ct, plain, plain_stride, out, size,
+                     nl, count, sub ? 2 : 1);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace abc

@@ -1,0 +1,165 @@
+// abc_kernels_ntt.hip -- stand-alone batched NTT / INTT launches (one workgroup per limb block).
+//
+// Replaces the ntt_negacyclic_harvey / inverse_ntt_negacyclic_harvey calls inside the seal::Evaluator,
+// BatchEncoder and Decryptor routines the reference invokes (src/runtime/SealCiphertext.cpp:104-105,
+// 122-123,159,196; src/runtime/SealCiphertextFactory.cpp:130,150-151).  N <= 2^14: one LDS-resident
+// pass per limb.  N = 2^15, 2^16: a strided register pass through HBM does the first (forward) / last
+// (inverse) logN-12 stages, then 4096-point LDS blocks do the rest -- no transpose is needed because the
+// Cooley-Tukey bit-reversed-output ordering keeps later stages block-local.
+#include "abc_context.hpp"
+
+namespace abc {
+
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data, LimbMap map, int nl, int S0) {
+  __shared__ u64 lds[lds_words(LB)];
+  const size_t limb = blockIdx.x >> S0;
+  const int b = blockIdx.x & ((1 << S0) - 1);
+  const int mid = map.id[limb % nl];
+  const Mod m = c.mods[mid];
+  const NttTable t = ntt_table(c, mid);
+  u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
+  ntt_fwd_block<LB>(
+      lds, [&](int i) { return base[i]; }, [&](int i, u64 v) { base[i] = canon4(v, m); }, t, m, S0, b);
+}
+
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv(DevCtx c, u64 *data, LimbMap map, int nl, int S0) {
+  __shared__ u64 lds[lds_words(LB)];
+  const size_t limb = blockIdx.x >> S0;
+  const int b = blockIdx.x & ((1 << S0) - 1);
+  const int mid = map.id[limb % nl];
+  const Mod m = c.mods[mid];
+  const NttTable t = ntt_table(c, mid);
+  u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
+  const bool whole = (S0 == 0);
+  ntt_inv_block<LB>(
+      lds, [&](int i) { return base[i]; }, [&](int i, u64 v) { base[i] = whole ? scale_inv_n(v, m) : v; }, t, m, S0, b);
+}
+
+// first R stages of a 2^logn-point forward transform, straight through HBM (coalesced: lane = p)
+template <int R>
+__global__ __launch_bounds__(256) void k_ntt_fwd_strided(DevCtx c, u64 *data, LimbMap map, int nl) {
+  const int G = c.n >> R;
+  const int per = G / 256;
+  const size_t limb = blockIdx.x / per;
+  const int p = (blockIdx.x % per) * 256 + threadIdx.x;
+  const int mid = map.id[limb % nl];
+  const Mod m = c.mods[mid];
+  const NttTable t = ntt_table(c, mid);
+  u64 *base = data + limb * (size_t)c.n + p;
+  u64 x[1 << R];
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) x[k] = base[(size_t)k * G];
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      const int idx = (1 << u) + (k >> (R - u));
+      const u64 w = t.tw[idx], ws = t.tws[idx];
+      u64 a = x[k] >= m.two_q ? x[k] - m.two_q : x[k];
+      u64 v = mul_shoup_lazy(x[k | half], w, ws, m.q);
+      x[k] = a + v;
+      x[k | half] = a + m.two_q - v;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) base[(size_t)k * G] = x[k];  // lazy [0,4q): block kernel guards
+}
+
+// last R stages of the inverse transform + N^-1 scaling
+template <int R>
+__global__ __launch_bounds__(256) void k_ntt_inv_strided(DevCtx c, u64 *data, LimbMap map, int nl) {
+  const int G = c.n >> R;
+  const int per = G / 256;
+  const size_t limb = blockIdx.x / per;
+  const int p = (blockIdx.x % per) * 256 + threadIdx.x;
+  const int mid = map.id[limb % nl];
+  const Mod m = c.mods[mid];
+  const NttTable t = ntt_table(c, mid);
+  u64 *base = data + limb * (size_t)c.n + p;
+  u64 x[1 << R];
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) x[k] = base[(size_t)k * G];
+#pragma unroll
+  for (int u = R - 1; u >= 0; u--) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      const int idx = (1 << u) + (k >> (R - u));
+      const u64 w = t.itw[idx], ws = t.itws[idx];
+      u64 a = x[k], b2 = x[k | half];
+      u64 s = a + b2;
+      x[k] = s >= m.two_q ? s - m.two_q : s;
+      x[k | half] = mul_shoup_lazy(a + m.two_q - b2, w, ws, m.q);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) base[(size_t)k * G] = scale_inv_n(x[k], m);
+}
+
+constexpr int kBigBlockLB = 12;  // LDS block size used under the strided pass for N > 2^14
+
+template <int LB>
+static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, int S0, bool fwd) {
+  dim3 grid((unsigned)(total_limbs << S0)), block((1 << LB) / 16);
+  if (fwd)
+    hipLaunchKernelGGL(k_ntt_fwd<LB>, grid, block, 0, c->stream, c->dc, d, map, nl, S0);
+  else
+    hipLaunchKernelGGL(k_ntt_inv<LB>, grid, block, 0, c->stream, c->dc, d, map, nl, S0);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+template <int R>
+static int launch_strided(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd) {
+  const int G = c->n >> R;
+  dim3 grid((unsigned)(total_limbs * (G / 256))), block(256);
+  if (fwd)
+    hipLaunchKernelGGL(k_ntt_fwd_strided<R>, grid, block, 0, c->stream, c->dc, d, map, nl);
+  else
+    hipLaunchKernelGGL(k_ntt_inv_strided<R>, grid, block, 0, c->stream, c->dc, d, map, nl);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd) {
+  if (total_limbs == 0) return 0;
+  switch (c->logn) {
+    case 10: return launch_block<10>(c, d, map, nl, total_limbs, 0, fwd);
+    case 11: return launch_block<11>(c, d, map, nl, total_limbs, 0, fwd);
+    case 12: return launch_block<12>(c, d, map, nl, total_limbs, 0, fwd);
+    case 13: return launch_block<13>(c, d, map, nl, total_limbs, 0, fwd);
+    case 14: return launch_block<14>(c, d, map, nl, total_limbs, 0, fwd);
+    case 15:
+    case 16: {
+      const int S0 = c->logn - kBigBlockLB;
+      if (fwd) {
+        int rc = (S0 == 3) ? launch_strided<3>(c, d, map, nl, total_limbs, true)
+                           : launch_strided<4>(c, d, map, nl, total_limbs, true);
+        if (rc) return rc;
+        return launch_block<kBigBlockLB>(c, d, map, nl, total_limbs, S0, true);
+      } else {
+        int rc = launch_block<kBigBlockLB>(c, d, map, nl, total_limbs, S0, false);
+        if (rc) return rc;
+        return (S0 == 3) ? launch_strided<3>(c, d, map, nl, total_limbs, false)
+                         : launch_strided<4>(c, d, map, nl, total_limbs, false);
+      }
+    }
+    default:
+      set_error("unsupported ring degree (logn must be 10..16)");
+      return 1;
+  }
+}
+
+int launch_ntt_fwd(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
+  return launch_ntt(c, d, map, nl, total_limbs, true);
+}
+int launch_ntt_inv(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
+  return launch_ntt(c, d, map, nl, total_limbs, false);
+}
+
+}  // namespace abc

@@ -1,0 +1,287 @@
+// abc_ntt.hpp -- LDS-staged negacyclic NTT / INTT building blocks for gfx950.
+//
+// One workgroup transforms one contiguous block of 2^LB coefficients (LB = 10..14: 8..128 KiB of the
+// CU's 160 KiB LDS) of one RNS limb.  Each thread keeps 16 coefficients in VGPRs and performs up to
+// four butterfly stages (radix-16) between two LDS exchanges, so a 2^14-point transform touches LDS
+// three times and HBM exactly once in and once out.  Ordering follows the reference's SEAL
+// dependency: forward = Cooley-Tukey, natural in -> bit-reversed out; inverse = Gentleman-Sande,
+// bit-reversed in -> natural out, with twiddles tw[m+i] = psi^bitrev(m+i) (psi = minimal primitive
+// 2N-th root) -- the layout every NTT-form ciphertext, key and plaintext of the reference's SEAL
+// runtime uses (call sites: src/runtime/SealCiphertext.cpp:104-105,122-123,159,196).
+// Butterflies are Harvey lazy ([0,4q) forward, [0,2q) inverse); callers canonicalise in the store
+// functor, so outputs are bit-exact with the oracle.
+//
+// A block may be a sub-transform of a larger N (N = 2^15, 2^16 do not fit LDS): the caller passes the
+// number of stages already done (S0) and the block index b, and the first S0 stages are done by the
+// strided global pass in abc_ntt.hip.
+#pragma once
+
+#include "abc_modarith.hpp"
+
+namespace abc {
+
+// LDS padding: 4 extra words every 64 keeps the stride-2^k accesses of the middle passes
+// conflict-free for ds_read_b64/ds_write_b64 (bank = (addr/4) mod 64).
+__device__ __forceinline__ int lds_pad(int i) { return i + ((i >> 6) << 2); }
+constexpr int lds_words(int lb) { return (1 << lb) + ((1 << lb) >> 6) * 4; }
+
+struct NttTable {
+  const u64 *tw;    // [N] forward twiddles, bit-reversed order
+  const u64 *tws;   // [N] Shoup quotients
+  const u64 *itw;   // [N] inverse twiddles (itw[m+i] = tw[m+i]^-1)
+  const u64 *itws;  // [N]
+};
+
+// ---- one radix-2^R register pass over NG = 16>>R groups -------------------------------------------
+// Forward (CT): stages S..S+R-1 of the block-local transform.
+template <int LB, int S, int R, bool UNIFORM>
+__device__ __forceinline__ void fwd_pass(u64 (&x)[16], const int (&hi)[16 >> R], const NttTable &t, u64 q, u64 two_q,
+                                         int S0, int b) {
+  constexpr int NG = 16 >> R;
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      // twiddle index of butterfly block: global stage S0+S+u
+      int base = (1 << (S0 + S + u)) + (b << (S + u)) + (hi[g] << u);
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) {
+        if (k & half) continue;
+        int idx = base + (k >> (R - u));
+        if (UNIFORM) idx = __builtin_amdgcn_readfirstlane(idx);
+        u64 w = t.tw[idx], ws = t.tws[idx];
+        u64 &X = x[g * (1 << R) + k];
+        u64 &Y = x[g * (1 << R) + (k | half)];
+        u64 a = X >= two_q ? X - two_q : X;
+        u64 v = mul_shoup_lazy(Y, w, ws, q);
+        X = a + v;
+        Y = a + two_q - v;
+      }
+    }
+  }
+}
+
+// Inverse (GS): stages S+R-1 .. S (reverse order). Inputs/outputs in [0,2q).
+template <int LB, int S, int R, bool UNIFORM>
+__device__ __forceinline__ void inv_pass(u64 (&x)[16], const int (&hi)[16 >> R], const NttTable &t, u64 q, u64 two_q,
+                                         int S0, int b) {
+  constexpr int NG = 16 >> R;
+#pragma unroll
+  for (int u = R - 1; u >= 0; u--) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      int base = (1 << (S0 + S + u)) + (b << (S + u)) + (hi[g] << u);
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) {
+        if (k & half) continue;
+        int idx = base + (k >> (R - u));
+        if (UNIFORM) idx = __builtin_amdgcn_readfirstlane(idx);
+        u64 w = t.itw[idx], ws = t.itws[idx];
+        u64 &X = x[g * (1 << R) + k];
+        u64 &Y = x[g * (1 << R) + (k | half)];
+        u64 a = X, c = Y;
+        u64 s = a + c;
+        X = s >= two_q ? s - two_q : s;
+        Y = mul_shoup_lazy(a + two_q - c, w, ws, q);
+      }
+    }
+  }
+}
+
+// Index bookkeeping of one pass: thread `tid` of T = 2^LB/16 owns groups p_g = tid + T*g; group p has
+// lo = p mod G, hi = p / G (G = 2^(LB-S-R)); its k-th element sits at (hi << (LB-S)) + (k << logG) + lo.
+template <int LB, int S, int R>
+struct PassIdx {
+  static constexpr int T = (1 << LB) / 16;
+  static constexpr int NG = 16 >> R;
+  static constexpr int LOGG = LB - S - R;
+  static constexpr int G = 1 << LOGG;
+  static constexpr bool UNIFORM = (G >= 64);  // all 64 lanes of a wave share hi
+  __device__ __forceinline__ static void groups(int tid, int (&hi)[NG], int (&lo)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      int p = tid + T * g;
+      hi[g] = p >> LOGG;
+      lo[g] = p & (G - 1);
+    }
+  }
+  __device__ __forceinline__ static int elem(int hi, int lo, int k) { return (hi << (LB - S)) + (k << LOGG) + lo; }
+};
+
+template <int LB, int S, int R>
+__device__ __forceinline__ void lds_load(const u64 *lds, u64 (&x)[16], const int (&hi)[16 >> R], const int (&lo)[16 >> R]) {
+  using P = PassIdx<LB, S, R>;
+#pragma unroll
+  for (int g = 0; g < P::NG; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = lds[lds_pad(P::elem(hi[g], lo[g], k))];
+}
+template <int LB, int S, int R>
+__device__ __forceinline__ void lds_store(u64 *lds, const u64 (&x)[16], const int (&hi)[16 >> R], const int (&lo)[16 >> R]) {
+  using P = PassIdx<LB, S, R>;
+#pragma unroll
+  for (int g = 0; g < P::NG; g++)
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) lds[lds_pad(P::elem(hi[g], lo[g], k))] = x[g * (1 << R) + k];
+}
+
+// Pass schedules (sum = LB, last forward pass has R = 2 so each lane ends with 32-byte contiguous runs).
+template <int LB> struct Sched;
+template <> struct Sched<10> { static constexpr int R0 = 4, R1 = 4, R2 = 2, R3 = 0; };
+template <> struct Sched<11> { static constexpr int R0 = 4, R1 = 3, R2 = 2, R3 = 2; };
+template <> struct Sched<12> { static constexpr int R0 = 4, R1 = 4, R2 = 2, R3 = 2; };
+template <> struct Sched<13> { static constexpr int R0 = 4, R1 = 4, R2 = 3, R3 = 2; };
+template <> struct Sched<14> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 = 2; };
+
+// ---- forward block transform -----------------------------------------------------------------------
+// load(i)  -> u64 in [0,4q)   coefficient i (block-local natural index)
+// store(i, v)                 v in [0,4q) lazily reduced value of output slot i (block-local,
+//                             bit-reversed order)
+template <int LB, class Load, class Store>
+__device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
+                                              int b) {
+  using SC = Sched<LB>;
+  const int tid = threadIdx.x;
+  const u64 q = m.q, two_q = m.two_q;
+  u64 x[16];
+  {  // pass 0: global -> regs -> LDS
+    constexpr int S = 0, R = SC::R0;
+    using P = PassIdx<LB, S, R>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(tid, hi, lo);
+#pragma unroll
+    for (int g = 0; g < P::NG; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(P::elem(hi[g], lo[g], k));
+    fwd_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    lds_store<LB, S, R>(lds, x, hi, lo);
+  }
+  __syncthreads();
+  {  // pass 1
+    constexpr int S = SC::R0, R = SC::R1;
+    using P = PassIdx<LB, S, R>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(tid, hi, lo);
+    lds_load<LB, S, R>(lds, x, hi, lo);
+    fwd_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    if constexpr (SC::R3 == 0 && SC::R2 == 0) {
+#pragma unroll
+      for (int g = 0; g < P::NG; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) store(P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
+      return;
+    } else {
+      lds_store<LB, S, R>(lds, x, hi, lo);  // in place: a thread rewrites exactly the words it read
+    }
+  }
+  __syncthreads();
+  {  // pass 2
+    constexpr int S = SC::R0 + SC::R1, R = SC::R2;
+    using P = PassIdx<LB, S, R>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(tid, hi, lo);
+    lds_load<LB, S, R>(lds, x, hi, lo);
+    fwd_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    if constexpr (SC::R3 == 0) {
+#pragma unroll
+      for (int g = 0; g < P::NG; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) store(P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
+      return;
+    } else {
+      lds_store<LB, S, R>(lds, x, hi, lo);  // in place: a thread rewrites exactly the words it read
+    }
+  }
+  if constexpr (SC::R3 != 0) {
+    __syncthreads();
+    constexpr int S = SC::R0 + SC::R1 + SC::R2, R = SC::R3;
+    using P = PassIdx<LB, S, R>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(tid, hi, lo);
+    lds_load<LB, S, R>(lds, x, hi, lo);
+    fwd_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+#pragma unroll
+    for (int g = 0; g < P::NG; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) store(P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
+  }
+}
+
+// ---- inverse block transform -----------------------------------------------------------------------
+// load(i)  -> u64 in [0,2q)   input slot i (block-local, bit-reversed order)
+// store(i, v)                 v in [0,2q): coefficient i BEFORE the N^-1 scaling (caller scales:
+//                             for a sub-block the scaling belongs to the final strided pass)
+template <int LB, class Load, class Store>
+__device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
+                                              int b) {
+  using SC = Sched<LB>;
+  const int tid = threadIdx.x;
+  const u64 q = m.q, two_q = m.two_q;
+  u64 x[16];
+  constexpr int SA = SC::R0, SB = SC::R0 + SC::R1, SCc = SC::R0 + SC::R1 + SC::R2;
+  if constexpr (SC::R3 != 0) {
+    constexpr int S = SCc, R = SC::R3;
+    using P = PassIdx<LB, S, R>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(tid, hi, lo);
+#pragma unroll
+    for (int g = 0; g < P::NG; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(P::elem(hi[g], lo[g], k));
+    inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    lds_store<LB, S, R>(lds, x, hi, lo);
+    __syncthreads();
+  }
+  {
+    constexpr int S = SB, R = SC::R2;
+    using P = PassIdx<LB, S, R>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(tid, hi, lo);
+    if constexpr (SC::R3 != 0) {
+      lds_load<LB, S, R>(lds, x, hi, lo);
+    } else {
+#pragma unroll
+      for (int g = 0; g < P::NG; g++)
+#pragma unroll
+        for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(P::elem(hi[g], lo[g], k));
+    }
+    inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    lds_store<LB, S, R>(lds, x, hi, lo);
+    __syncthreads();
+  }
+  {
+    constexpr int S = SA, R = SC::R1;
+    using P = PassIdx<LB, S, R>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(tid, hi, lo);
+    lds_load<LB, S, R>(lds, x, hi, lo);
+    inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    lds_store<LB, S, R>(lds, x, hi, lo);
+    __syncthreads();
+  }
+  {
+    constexpr int S = 0, R = SC::R0;
+    using P = PassIdx<LB, S, R>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(tid, hi, lo);
+    lds_load<LB, S, R>(lds, x, hi, lo);
+    inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+#pragma unroll
+    for (int g = 0; g < P::NG; g++)
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) store(P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
+  }
+}
+
+// lazily reduced [0,4q) -> [0,q)
+__device__ __forceinline__ u64 canon4(u64 v, const Mod &m) {
+  if (v >= m.two_q) v -= m.two_q;
+  if (v >= m.q) v -= m.q;
+  return v;
+}
+// scale by N^-1 and canonicalise (input [0,2q) or any 64-bit value)
+__device__ __forceinline__ u64 scale_inv_n(u64 v, const Mod &m) { return mul_shoup(v, m.inv_n, m.inv_n_s, m.q); }
+
+}  // namespace abc
