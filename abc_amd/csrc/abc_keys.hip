@@ -217,6 +217,7 @@ int keygen(abc_hip_ctx *c, uint64_t seed) {
     elts.push_back((uint32_t)neg); neg = (neg * neg) & (m - 1);
   }
   for (uint32_t elt : elts) {
+    if (c->d_galois.count(elt)) continue;  // 3^(N/4) = 3^-(N/4) mod 2N is listed twice: first key wins
     u64 *d_key = nullptr;
     ABC_HIP_CHECK(hipMalloc(&d_key, c->key_words() * 8));
     if (launch_galois(c, c->d_sk, d_newkey, K, 1, elt, true)) return 1;

@@ -159,13 +159,20 @@ int orc_keygen(orc_ctx *c, uint64_t seed) {
     elts[ne++] = (uint32_t)pos; pos = (pos * pos) & (m - 1);
     elts[ne++] = (uint32_t)neg; neg = (neg * neg) & (m - 1);
   }
+  int nk = 0;
   for (int e = 0; e < ne; e++) {
+    /* [SEAL-recall: KeyGenerator::create_galois_keys] "do we already have the key?" -> skip
+     * (3^(N/4) == 3^-(N/4) mod 2N, so the default list names that element twice) */
+    int dup = 0;
+    for (int d = 0; d < nk; d++) dup |= (c->gal_elt[d] == elts[e]);
+    if (dup) continue;
     for (int j = 0; j < K; j++) galois_ntt_one(c->sk_ntt + (size_t)j * n, s2 + (size_t)j * n, c->logn, elts[e]);
-    c->gal_elt[e] = elts[e];
-    c->gal_key[e] = (uint64_t *)malloc(key_words * 8);
-    make_kswitch_key(c, &rng, s2, c->gal_key[e]);
+    c->gal_elt[nk] = elts[e];
+    c->gal_key[nk] = (uint64_t *)malloc(key_words * 8);
+    make_kswitch_key(c, &rng, s2, c->gal_key[nk]);
+    nk++;
   }
-  c->ngal = ne;
+  c->ngal = nk;
   free(s2);
   return 0;
 }
