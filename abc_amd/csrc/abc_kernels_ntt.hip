@@ -20,7 +20,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data,
   const NttTable t = ntt_table(c, mid);
   u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
   ntt_fwd_block<LB>(
-      lds, [&](int i) { return base[i]; }, [&](int i, u64 v) { base[i] = canon4(v, m); }, t, m, S0, b);
+      lds, [&](int, int i) { return base[i]; }, [&](int, int i, u64 v) { base[i] = canon4(v, m); }, t, m, S0, b);
 }
 
 template <int LB>
@@ -34,7 +34,8 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv(DevCtx c, u64 *data,
   u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
   const bool whole = (S0 == 0);
   ntt_inv_block<LB>(
-      lds, [&](int i) { return base[i]; }, [&](int i, u64 v) { base[i] = whole ? scale_inv_n(v, m) : v; }, t, m, S0, b);
+      lds, [&](int, int i) { return base[i]; }, [&](int, int i, u64 v) { base[i] = whole ? scale_inv_n(v, m) : v; }, t, m,
+      S0, b);
 }
 
 // first R stages of a 2^logn-point forward transform, straight through HBM (coalesced: lane = p)

@@ -102,7 +102,4 @@ int microbench(abc_hip_ctx *c, int which, int iters, double *ms) {
   return 0;
 }
 
-// placeholder until the fused kernels land: -1 = "not applicable, use the generic path"
-int ckks_mul_relin_fused(abc_hip_ctx *, const u64 *, const u64 *, u64 *, int, size_t) { return -1; }
-
 }  // namespace abc

@@ -136,9 +136,11 @@ template <> struct Sched<13> { static constexpr int R0 = 4, R1 = 4, R2 = 3, R3 =
 template <> struct Sched<14> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 = 2; };
 
 // ---- forward block transform -----------------------------------------------------------------------
-// load(i)  -> u64 in [0,4q)   coefficient i (block-local natural index)
-// store(i, v)                 v in [0,4q) lazily reduced value of output slot i (block-local,
-//                             bit-reversed order)
+// load(r, i)  -> u64 in [0,4q)  coefficient i (block-local natural index) for register slot r
+// store(r, i, v)               v in [0,4q) lazily reduced value of output slot i (block-local,
+//                              bit-reversed order) held in register slot r (r is a compile-time
+//                              constant after unrolling, so callers may index register arrays with it)
+// The final register layout is PassIdx<LB, LB-2, 2>: slot r = 4g+k holds element 4*(tid + T*g) + k.
 template <int LB, class Load, class Store>
 __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
                                               int b) {
@@ -154,7 +156,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
 #pragma unroll
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(P::elem(hi[g], lo[g], k));
+      for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
     fwd_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
   }
@@ -170,7 +172,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
 #pragma unroll
       for (int g = 0; g < P::NG; g++)
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) store(P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
+        for (int k = 0; k < (1 << R); k++) store(g * (1 << R) + k, P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
       return;
     } else {
       lds_store<LB, S, R>(lds, x, hi, lo);  // in place: a thread rewrites exactly the words it read
@@ -188,7 +190,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
 #pragma unroll
       for (int g = 0; g < P::NG; g++)
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) store(P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
+        for (int k = 0; k < (1 << R); k++) store(g * (1 << R) + k, P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
       return;
     } else {
       lds_store<LB, S, R>(lds, x, hi, lo);  // in place: a thread rewrites exactly the words it read
@@ -205,14 +207,15 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
 #pragma unroll
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << R); k++) store(P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
+      for (int k = 0; k < (1 << R); k++) store(g * (1 << R) + k, P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
   }
 }
 
 // ---- inverse block transform -----------------------------------------------------------------------
-// load(i)  -> u64 in [0,2q)   input slot i (block-local, bit-reversed order)
-// store(i, v)                 v in [0,2q): coefficient i BEFORE the N^-1 scaling (caller scales:
-//                             for a sub-block the scaling belongs to the final strided pass)
+// load(r, i)  -> u64 in [0,2q)  input slot i (block-local, bit-reversed order); same register layout
+//                              as the forward transform's final one
+// store(r, i, v)               v in [0,2q): coefficient i BEFORE the N^-1 scaling (caller scales:
+//                              for a sub-block the scaling belongs to the final strided pass)
 template <int LB, class Load, class Store>
 __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
                                               int b) {
@@ -229,7 +232,7 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
 #pragma unroll
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(P::elem(hi[g], lo[g], k));
+      for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
     inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
     __syncthreads();
@@ -245,7 +248,7 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
 #pragma unroll
       for (int g = 0; g < P::NG; g++)
 #pragma unroll
-        for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(P::elem(hi[g], lo[g], k));
+        for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
     }
     inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
@@ -271,7 +274,7 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
 #pragma unroll
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
-      for (int k = 0; k < (1 << R); k++) store(P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
+      for (int k = 0; k < (1 << R); k++) store(g * (1 << R) + k, P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
   }
 }
 
