@@ -1,0 +1,188 @@
+#include "HipCiphertext.hpp"
+
+#include "../../include/abc_hip.h"
+#include "HipCiphertextFactory.hpp"
+
+void abcHipCheck(int status, const char *what) {
+  if (status != 0) throw std::runtime_error(std::string(what) + ": " + abc_hip_last_error());
+}
+
+namespace {
+const HipCiphertext &cast(const AbstractCiphertext &c) {
+  if (auto p = dynamic_cast<const HipCiphertext *>(&c)) return *p;
+  throw std::runtime_error("Cast of AbstractCiphertext to HipCiphertext failed!");
+}
+const Cleartext<int> &intCleartext(const ICleartext &operand, const char *op) {
+  if (auto p = dynamic_cast<const Cleartext<int> *>(&operand)) return *p;
+  throw std::runtime_error(std::string(op) + "(Ciphertext,Cleartext) requires a Cleartext<int> as BFV supports integers only.");
+}
+struct DevicePlain {  // RAII for the per-call plaintext the reference also re-encodes on every plain op
+  const HipCiphertextFactory &f;
+  uint64_t *p;
+  DevicePlain(const HipCiphertextFactory &fac, const std::vector<int> &v) : f(fac), p(fac.createPlaintext(v)) {}
+  ~DevicePlain() { f.freeDevice(p); }
+};
+}  // namespace
+
+HipCiphertext::HipCiphertext(const std::reference_wrapper<const HipCiphertextFactory> hipFactory)
+    : AbstractCiphertext((const std::reference_wrapper<const AbstractCiphertextFactory>)hipFactory) {
+  void *p = nullptr;
+  abcHipCheck(abc_hip_malloc(hipFactory.get().context(), &p, hipFactory.get().ciphertextWords() * 8), "ciphertext allocation");
+  d_data = static_cast<uint64_t *>(p);
+}
+
+HipCiphertext::~HipCiphertext() { release(); }
+
+void HipCiphertext::release() noexcept {
+  if (!d_data) return;
+  if (auto f = dynamic_cast<const HipCiphertextFactory *>(&factory.get())) abc_hip_free(f->context(), d_data);
+  d_data = nullptr;
+}
+
+HipCiphertext::HipCiphertext(const HipCiphertext &other) : HipCiphertext(std::cref(other.getFactory())) {
+  // deep copy: the interpreter clones on every variable read (src/runtime/RuntimeVisitor.cpp:431-437)
+  abcHipCheck(abc_hip_memcpy_d2d(getFactory().context(), d_data, other.d_data, getFactory().ciphertextWords() * 8), "clone");
+}
+
+HipCiphertext::HipCiphertext(HipCiphertext &&other) noexcept : AbstractCiphertext(other.factory), d_data(other.d_data) {
+  other.d_data = nullptr;
+}
+
+HipCiphertext &HipCiphertext::operator=(const HipCiphertext &other) { return *this = HipCiphertext(other); }
+
+HipCiphertext &HipCiphertext::operator=(HipCiphertext &&other) {
+  if (&other == this) return *this;
+  if (&factory.get() != &other.factory.get())
+    throw std::runtime_error("Cannot move Ciphertext from factory A into Ciphertext created by Factory B.");
+  release();
+  d_data = other.d_data;
+  other.d_data = nullptr;
+  return *this;
+}
+
+const HipCiphertextFactory &HipCiphertext::getFactory() const {
+  if (auto f = dynamic_cast<const HipCiphertextFactory *>(&factory.get())) return *f;
+  throw std::runtime_error("Cast of AbstractFactory to HipFactory failed. HipCiphertext is probably invalid.");
+}
+
+std::unique_ptr<HipCiphertext> HipCiphertext::fresh() const { return std::make_unique<HipCiphertext>(std::cref(getFactory())); }
+std::unique_ptr<HipCiphertext> HipCiphertext::clone_impl() const { return std::make_unique<HipCiphertext>(*this); }
+std::unique_ptr<AbstractCiphertext> HipCiphertext::clone() const { return clone_impl(); }
+
+int HipCiphertext::noiseBits() const {
+  throw std::runtime_error("noiseBits: invariant noise budget is a host-side diagnostic not provided by the HIP backend.");
+}
+
+// ---- ctxt-ctxt ----
+std::unique_ptr<AbstractCiphertext> HipCiphertext::add(const AbstractCiphertext &operand) const {
+  auto r = fresh();
+  abcHipCheck(abc_hip_add(getFactory().context(), d_data, cast(operand).d_data, r->d_data, 2, getFactory().dataLimbs(), 1), "add");
+  return r;
+}
+std::unique_ptr<AbstractCiphertext> HipCiphertext::subtract(const AbstractCiphertext &operand) const {
+  auto r = fresh();
+  abcHipCheck(abc_hip_sub(getFactory().context(), d_data, cast(operand).d_data, r->d_data, 2, getFactory().dataLimbs(), 1), "sub");
+  return r;
+}
+std::unique_ptr<AbstractCiphertext> HipCiphertext::multiply(const AbstractCiphertext &operand) const {
+  // Evaluator::multiply + relinearize_inplace, src/runtime/SealCiphertext.cpp:102-107
+  auto r = fresh();
+  abcHipCheck(abc_hip_mul_relin(getFactory().context(), d_data, cast(operand).d_data, r->d_data, getFactory().dataLimbs(), 1),
+              "multiply");
+  return r;
+}
+void HipCiphertext::addInplace(const AbstractCiphertext &operand) {
+  abcHipCheck(abc_hip_add(getFactory().context(), d_data, cast(operand).d_data, d_data, 2, getFactory().dataLimbs(), 1), "add");
+}
+void HipCiphertext::subtractInplace(const AbstractCiphertext &operand) {
+  abcHipCheck(abc_hip_sub(getFactory().context(), d_data, cast(operand).d_data, d_data, 2, getFactory().dataLimbs(), 1), "sub");
+}
+void HipCiphertext::multiplyInplace(const AbstractCiphertext &operand) {
+  abcHipCheck(abc_hip_mul_relin(getFactory().context(), d_data, cast(operand).d_data, d_data, getFactory().dataLimbs(), 1),
+              "multiply");
+}
+
+// ---- rotation ----
+std::unique_ptr<AbstractCiphertext> HipCiphertext::rotateRows(int steps) const {
+  auto r = fresh();
+  abcHipCheck(abc_hip_rotate(getFactory().context(), d_data, r->d_data, getFactory().dataLimbs(), steps, 1), "rotate_rows");
+  return r;
+}
+void HipCiphertext::rotateRowsInplace(int steps) {
+  abcHipCheck(abc_hip_rotate(getFactory().context(), d_data, d_data, getFactory().dataLimbs(), steps, 1), "rotate_rows");
+}
+
+// ---- ctxt-plain ----
+std::unique_ptr<AbstractCiphertext> HipCiphertext::addPlain(const ICleartext &operand) const {
+  auto r = clone_impl();
+  r->addPlainInplace(operand);
+  return r;
+}
+std::unique_ptr<AbstractCiphertext> HipCiphertext::subtractPlain(const ICleartext &operand) const {
+  auto r = clone_impl();
+  r->subtractPlainInplace(operand);
+  return r;
+}
+std::unique_ptr<AbstractCiphertext> HipCiphertext::multiplyPlain(const ICleartext &operand) const {
+  auto r = clone_impl();
+  r->multiplyPlainInplace(operand);
+  return r;
+}
+void HipCiphertext::addPlainInplace(const ICleartext &operand) {
+  DevicePlain pl(getFactory(), intCleartext(operand, "ADD").getData());
+  abcHipCheck(abc_hip_add_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), 1), "add_plain");
+}
+void HipCiphertext::subtractPlainInplace(const ICleartext &operand) {
+  DevicePlain pl(getFactory(), intCleartext(operand, "SUB").getData());
+  abcHipCheck(abc_hip_sub_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), 1), "sub_plain");
+}
+void HipCiphertext::multiplyPlainInplace(const ICleartext &operand) {
+  const auto &ct = intCleartext(operand, "MULTIPLY");
+  if (ct.allEqual(-1)) {  // negation shortcut, src/runtime/SealCiphertext.cpp:192-193
+    abcHipCheck(abc_hip_negate(getFactory().context(), d_data, d_data, 2, getFactory().dataLimbs(), 1), "negate");
+    return;
+  }
+  DevicePlain pl(getFactory(), ct.getData());
+  // multiply_plain keeps size 2, so the reference's relinearize_inplace (:197) is a no-op
+  abcHipCheck(abc_hip_multiply_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), 1),
+              "multiply_plain");
+}
+
+// ---- AbstractValue dispatch (src/runtime/SealCiphertext.cpp:208-239) ----
+void HipCiphertext::add_inplace(const AbstractValue &other) {
+  if (auto c = dynamic_cast<const HipCiphertext *>(&other)) addInplace(*c);
+  else if (auto p = dynamic_cast<const ICleartext *>(&other)) addPlainInplace(*p);
+  else throw std::runtime_error("Operation ADD only supported for (AbstractCiphertext,AbstractCiphertext) and (HipCiphertext, ICleartext).");
+}
+void HipCiphertext::subtract_inplace(const AbstractValue &other) {
+  if (auto c = dynamic_cast<const HipCiphertext *>(&other)) subtractInplace(*c);
+  else if (auto p = dynamic_cast<const ICleartext *>(&other)) subtractPlainInplace(*p);
+  else throw std::runtime_error("Operation SUBTRACT only supported for (HipCiphertext,HipCiphertext) and (HipCiphertext, ICleartext).");
+}
+void HipCiphertext::multiply_inplace(const AbstractValue &other) {
+  if (auto c = dynamic_cast<const HipCiphertext *>(&other)) multiplyInplace(*c);
+  else if (auto p = dynamic_cast<const ICleartext *>(&other)) multiplyPlainInplace(*p);
+  else throw std::runtime_error("Operation MULTIPLY only supported for (HipCiphertext,HipCiphertext) and (HipCiphertext, ICleartext).");
+}
+#define ABC_UNSUPPORTED(name) \
+  void HipCiphertext::name(const AbstractValue &) { throw std::runtime_error("Operation " #name " not supported for (HipCiphertext, ANY)."); }
+ABC_UNSUPPORTED(divide_inplace)
+ABC_UNSUPPORTED(modulo_inplace)
+ABC_UNSUPPORTED(logicalAnd_inplace)
+ABC_UNSUPPORTED(logicalOr_inplace)
+ABC_UNSUPPORTED(logicalLess_inplace)
+ABC_UNSUPPORTED(logicalLessEqual_inplace)
+ABC_UNSUPPORTED(logicalGreater_inplace)
+ABC_UNSUPPORTED(logicalGreaterEqual_inplace)
+ABC_UNSUPPORTED(logicalEqual_inplace)
+ABC_UNSUPPORTED(logicalNotEqual_inplace)
+ABC_UNSUPPORTED(bitwiseAnd_inplace)
+ABC_UNSUPPORTED(bitwiseXor_inplace)
+ABC_UNSUPPORTED(bitwiseOr_inplace)
+#undef ABC_UNSUPPORTED
+void HipCiphertext::logicalNot_inplace() {
+  throw std::runtime_error("Operation logicalNot_inplace not supported for (HipCiphertext, ANY). For an arithmetic negation, multiply_inplace by (-1) instead.");
+}
+void HipCiphertext::bitwiseNot_inplace() {
+  throw std::runtime_error("Operation bitwiseNot_inplace not supported for (HipCiphertext, ANY). For an arithmetic negation, multiply_inplace by (-1) instead.");
+}

@@ -1,0 +1,67 @@
+// HipCiphertext -- an AbstractCiphertext whose data lives in MI355X HBM and whose every operation is a call
+// into libabc_hip.so (include/abc_hip.h).  Drop-in counterpart of the reference's SealCiphertext
+// (include/ast_opt/runtime/SealCiphertext.h:14-112, src/runtime/SealCiphertext.cpp): same methods, same
+// operator set (add / subtract / multiply supported, the other 15 AbstractValue operators throw
+// std::runtime_error, src/runtime/SealCiphertext.cpp:241-309), same ownership (unique_ptr to the
+// ciphertext, non-owning reference to the factory, cross-factory move-assign throws, :25-34).
+#pragma once
+
+#include "plugin_api.hpp"
+
+#include "HipCiphertextFactory.hpp"
+
+class HipCiphertext : public AbstractCiphertext {
+  uint64_t *d_data = nullptr;  // device buffer [2][L][N]; owned
+
+  std::unique_ptr<HipCiphertext> clone_impl() const;
+  std::unique_ptr<HipCiphertext> fresh() const;
+  void release() noexcept;
+
+ public:
+  ~HipCiphertext() override;
+  explicit HipCiphertext(const std::reference_wrapper<const HipCiphertextFactory> hipFactory);
+  HipCiphertext(const HipCiphertext &other);
+  HipCiphertext(HipCiphertext &&other) noexcept;
+  HipCiphertext &operator=(const HipCiphertext &other);
+  HipCiphertext &operator=(HipCiphertext &&other);
+
+  [[nodiscard]] const uint64_t *devicePtr() const { return d_data; }
+  [[nodiscard]] uint64_t *devicePtr() { return d_data; }
+  [[nodiscard]] const HipCiphertextFactory &getFactory() const override;
+  [[nodiscard]] int noiseBits() const;  // SealCiphertext::noiseBits, SealCiphertext.cpp:80-83 (host-side diagnostic)
+
+  std::unique_ptr<AbstractCiphertext> multiply(const AbstractCiphertext &operand) const override;
+  void multiplyInplace(const AbstractCiphertext &operand) override;
+  std::unique_ptr<AbstractCiphertext> multiplyPlain(const ICleartext &operand) const override;
+  void multiplyPlainInplace(const ICleartext &operand) override;
+  std::unique_ptr<AbstractCiphertext> add(const AbstractCiphertext &operand) const override;
+  void addInplace(const AbstractCiphertext &operand) override;
+  std::unique_ptr<AbstractCiphertext> addPlain(const ICleartext &operand) const override;
+  void addPlainInplace(const ICleartext &operand) override;
+  std::unique_ptr<AbstractCiphertext> subtract(const AbstractCiphertext &operand) const override;
+  void subtractInplace(const AbstractCiphertext &operand) override;
+  std::unique_ptr<AbstractCiphertext> subtractPlain(const ICleartext &operand) const override;
+  void subtractPlainInplace(const ICleartext &operand) override;
+  std::unique_ptr<AbstractCiphertext> rotateRows(int steps) const override;
+  void rotateRowsInplace(int steps) override;
+  std::unique_ptr<AbstractCiphertext> clone() const override;
+
+  void add_inplace(const AbstractValue &other) override;
+  void subtract_inplace(const AbstractValue &other) override;
+  void multiply_inplace(const AbstractValue &other) override;
+  void divide_inplace(const AbstractValue &other) override;
+  void modulo_inplace(const AbstractValue &other) override;
+  void logicalAnd_inplace(const AbstractValue &other) override;
+  void logicalOr_inplace(const AbstractValue &other) override;
+  void logicalLess_inplace(const AbstractValue &other) override;
+  void logicalLessEqual_inplace(const AbstractValue &other) override;
+  void logicalGreater_inplace(const AbstractValue &other) override;
+  void logicalGreaterEqual_inplace(const AbstractValue &other) override;
+  void logicalEqual_inplace(const AbstractValue &other) override;
+  void logicalNotEqual_inplace(const AbstractValue &other) override;
+  void logicalNot_inplace() override;
+  void bitwiseAnd_inplace(const AbstractValue &other) override;
+  void bitwiseXor_inplace(const AbstractValue &other) override;
+  void bitwiseOr_inplace(const AbstractValue &other) override;
+  void bitwiseNot_inplace() override;
+};

@@ -1,0 +1,52 @@
+// HipCiphertextFactory -- AbstractCiphertextFactory over libabc_hip.so.  Drop-in counterpart of
+// SealCiphertextFactory (include/ast_opt/runtime/SealCiphertextFactory.h:13-120,
+// src/runtime/SealCiphertextFactory.cpp): BFV, N = numElementsPerCiphertextSlot (default 16384, :16),
+// coefficient modulus BFVDefault(N) (:80), plaintext modulus Batching(N, 20) (:83), secret / public /
+// relinearisation / all default Galois keys (:89-93), pad-with-last-value (:102-115).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "plugin_api.hpp"
+
+struct abc_hip_ctx;
+
+class HipCiphertextFactory : public AbstractCiphertextFactory {
+  const unsigned int ciphertextSlotSize = 16'384;
+  abc_hip_ctx *ctx = nullptr;  // owned: device tables + keys
+  int limbs = 0;               // data limbs L
+  uint64_t keySeed = 0;
+
+  void setupContext(int device);
+  template <typename T>
+  std::vector<T> expandVector(const std::vector<T> &values) const;
+
+ public:
+  HipCiphertextFactory();
+  explicit HipCiphertextFactory(unsigned int numElementsPerCiphertextSlot, int device = 0, uint64_t seed = 0);
+  ~HipCiphertextFactory() override;
+  HipCiphertextFactory(const HipCiphertextFactory &) = delete;  // one device context per factory
+  HipCiphertextFactory &operator=(const HipCiphertextFactory &) = delete;
+
+  [[nodiscard]] abc_hip_ctx *context() const { return ctx; }
+  [[nodiscard]] unsigned int getCiphertextSlotSize() const { return ciphertextSlotSize; }
+  [[nodiscard]] int dataLimbs() const { return limbs; }
+  [[nodiscard]] size_t ciphertextWords() const { return (size_t)2 * limbs * ciphertextSlotSize; }
+
+  // device plaintext [N] (coefficients mod t) from public values; caller frees with freeDevice
+  uint64_t *createPlaintext(const std::vector<int> &value) const;
+  uint64_t *createPlaintext(const std::vector<int64_t> &value) const;
+  uint64_t *createPlaintext(int64_t value) const;
+  void freeDevice(void *p) const;
+
+  std::unique_ptr<AbstractCiphertext> createCiphertext(const std::vector<int64_t> &data) const override;
+  std::unique_ptr<AbstractCiphertext> createCiphertext(const std::vector<int> &data) const override;
+  std::unique_ptr<AbstractCiphertext> createCiphertext(int64_t data) const override;
+  std::unique_ptr<AbstractCiphertext> createCiphertext(std::unique_ptr<AbstractValue> &&abstractValue) const override;
+  void decryptCiphertext(AbstractCiphertext &abstractCiphertext, std::vector<int64_t> &ciphertextData) const override;
+  std::string getString(AbstractCiphertext &abstractCiphertext) const override;
+};
+
+// maps a non-zero C-ABI status to the reference's error convention (std::runtime_error)
+void abcHipCheck(int status, const char *what);
