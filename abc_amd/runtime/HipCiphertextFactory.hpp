@@ -25,7 +25,7 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
  public:
   HipCiphertextFactory();
   explicit HipCiphertextFactory(unsigned int numElementsPerCiphertextSlot, int device = 0, uint64_t seed = 0);
-  ~HipCiphertextFactory() override;
+  virtual ~HipCiphertextFactory();  // (ABC's AbstractCiphertextFactory declares no virtual destructor)
   HipCiphertextFactory(const HipCiphertextFactory &) = delete;  // one device context per factory
   HipCiphertextFactory &operator=(const HipCiphertextFactory &) = delete;
 

@@ -21,3 +21,11 @@ cat "$OUT/sources.txt" | xargs -P 8 -I{} sh -c 'o="'"$OUT"'/obj/$(echo {} | sed 
 ar rcs "$OUT/libabc_ref.a" "$OUT"/obj/*.o
 g++ $CXXFLAGS "$HERE/ref_dummy_driver.cpp" "$OUT/libabc_ref.a" -o "$OUT/ref_dummy_driver"
 echo "built $OUT/ref_dummy_driver"
+# drop-in proof: the reference's RuntimeVisitor over this repo's HipCiphertextFactory, through ABC's real headers
+RT="$HERE/../abc_amd/runtime"
+if [ -f "$HERE/../abc_amd/libabc_hip.so" ]; then
+  g++ $CXXFLAGS -DABC_HIP_USE_REFERENCE_HEADERS -I"$RT" "$HERE/ref_hip_dropin.cpp" "$RT/HipCiphertext.cpp" \
+      "$RT/HipCiphertextFactory.cpp" "$OUT/libabc_ref.a" -L"$HERE/../abc_amd" -labc_hip \
+      -Wl,-rpath,'$ORIGIN/../../abc_amd' -o "$OUT/ref_hip_dropin"
+  echo "built $OUT/ref_hip_dropin"
+fi
