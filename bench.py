@@ -131,9 +131,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(tt[0]), float(tt[1])
         # the path's only exchange: gather the result ciphertexts of the last step on rank 0
-        gathered = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
-        dist.gather(out, gathered, dst=0)
+        from abc_amd.sharding import gather_results
+        gathered = gather_results(out, B * world, dst=0)
         torch.cuda.synchronize()
+        if rank == 0:
+            assert gathered.shape[0] == B * world
 
     if rank == 0:
         total_ops = B * world * args.steps
