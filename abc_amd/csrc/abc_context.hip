@@ -410,8 +410,13 @@ int abc_hip_ctx_create(int scheme, int logn, const uint64_t *primes, int nprimes
   } catch (const std::exception &e) {
     set_error(e.what());
   }
-  if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)) {
-    set_error("hipEventCreate failed");
+  if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+              hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming) != hipSuccess ||
+              hipEventCreateWithFlags(&c->lane_join[0], hipEventDisableTiming) != hipSuccess ||
+              hipEventCreateWithFlags(&c->lane_join[1], hipEventDisableTiming) != hipSuccess ||
+              hipStreamCreateWithFlags(&c->lane[0], hipStreamNonBlocking) != hipSuccess ||
+              hipStreamCreateWithFlags(&c->lane[1], hipStreamNonBlocking) != hipSuccess)) {
+    set_error("hipEventCreate / hipStreamCreate failed");
     rc = 1;
   }
   if (rc) { abc_hip_ctx_destroy(c); return 1; }
@@ -429,6 +434,11 @@ void abc_hip_ctx_destroy(abc_hip_ctx *c) {
   (void)hipFree(c->ws);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->lane_fork) (void)hipEventDestroy(c->lane_fork);
+  for (int i = 0; i < 2; i++) {
+    if (c->lane_join[i]) (void)hipEventDestroy(c->lane_join[i]);
+    if (c->lane[i]) (void)hipStreamDestroy(c->lane[i]);
+  }
   delete c;
 }
 

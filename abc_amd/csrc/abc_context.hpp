@@ -73,6 +73,9 @@ struct abc_hip_ctx {
   uint64_t t = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // two internal lanes let an HBM-streaming kernel of one chunk overlap an ALU-bound transform of another
+  hipStream_t lane[2] = {nullptr, nullptr};
+  hipEvent_t lane_fork = nullptr, lane_join[2] = {nullptr, nullptr};
   // moduli: ids 0..K-1 key primes, then Bsk (B_0..B_{nB-1}, m_sk), gamma, t, m_tilde(arith only)
   std::vector<abc::Mod> h_mods;
   std::vector<uint64_t> mod_values;

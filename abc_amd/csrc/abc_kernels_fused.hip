@@ -169,26 +169,41 @@ static inline unsigned stream_grid(size_t items, int block) {
 static inline size_t fused_scratch_limbs(int nl) { return (size_t)nl * (nl + 1) + 6 * (size_t)nl + 4; }
 
 template <int LB>
-static int run_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count, size_t chunk) {
+static int run_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count, size_t chunk, int lanes) {
   const size_t N = (size_t)1 << LB;
-  if (ensure_workspace(c, chunk * fused_scratch_limbs(nl) * N * 8)) return 1;
-  u64 *c2coef = (u64 *)c->ws, *c2ntt = c2coef + chunk * nl * N;
-  u64 *dec = c2ntt + chunk * nl * N;
-  u64 *ksacc = dec + chunk * nl * (nl + 1) * N, *tsp = ksacc + chunk * 2 * nl * N;
-  u64 *tlast = tsp + chunk * 2 * N, *c01 = tlast + chunk * 2 * N;
+  const size_t per_ct = fused_scratch_limbs(nl) * N;
+  if (ensure_workspace(c, (size_t)lanes * chunk * per_ct * 8)) return 1;
   const dim3 block((1 << LB) / 16);
-  for (size_t off = 0; off < count; off += chunk) {
+  if (lanes > 1) {  // fork: the lanes start after everything already queued on the caller's stream
+    ABC_HIP_CHECK(hipEventRecord(c->lane_fork, c->stream));
+    for (int l = 0; l < lanes; l++) ABC_HIP_CHECK(hipStreamWaitEvent(c->lane[l], c->lane_fork, 0));
+  }
+  int turn = 0;
+  for (size_t off = 0; off < count; off += chunk, turn++) {
     const size_t cc = (count - off < chunk) ? count - off : chunk;
+    const int l = (lanes > 1) ? turn % lanes : 0;
+    hipStream_t st = (lanes > 1) ? c->lane[l] : c->stream;
+    u64 *base = (u64 *)c->ws + (size_t)l * chunk * per_ct;
+    u64 *c2coef = base, *c2ntt = c2coef + chunk * nl * N;
+    u64 *dec = c2ntt + chunk * nl * N;
+    u64 *ksacc = dec + chunk * nl * (nl + 1) * N, *tsp = ksacc + chunk * 2 * nl * N;
+    u64 *tlast = tsp + chunk * 2 * N, *c01 = tlast + chunk * 2 * N;
     const size_t ctw = 2 * (size_t)nl * N;
-    hipLaunchKernelGGL(k_fused_tensor_intt<LB>, dim3((unsigned)(cc * nl)), block, 0, c->stream, c->dc, a + off * ctw, b + off * ctw,
-                       c01, c2coef, c2ntt, nl);
-    hipLaunchKernelGGL(k_fused_ks_decomp_ntt<LB>, dim3((unsigned)(cc * (nl + 1) * nl)), block, 0, c->stream, c->dc, c2coef, dec, nl);
-    hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, c->stream, c->dc, dec, c2ntt,
+    hipLaunchKernelGGL(k_fused_tensor_intt<LB>, dim3((unsigned)(cc * nl)), block, 0, st, c->dc, a + off * ctw, b + off * ctw, c01,
+                       c2coef, c2ntt, nl);
+    hipLaunchKernelGGL(k_fused_ks_decomp_ntt<LB>, dim3((unsigned)(cc * (nl + 1) * nl)), block, 0, st, c->dc, c2coef, dec, nl);
+    hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, dec, c2ntt,
                        c->d_relin, ksacc, tsp, nl, cc);
-    hipLaunchKernelGGL(k_fused_ks_special_intt<LB>, dim3((unsigned)(cc * 2)), block, 0, c->stream, c->dc, tsp, tlast);
-    hipLaunchKernelGGL(k_fused_ks_moddown<LB>, dim3((unsigned)(cc * 2 * nl)), block, 0, c->stream, c->dc, ksacc, tlast, c01,
+    hipLaunchKernelGGL(k_fused_ks_special_intt<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, tsp, tlast);
+    hipLaunchKernelGGL(k_fused_ks_moddown<LB>, dim3((unsigned)(cc * 2 * nl)), block, 0, st, c->dc, ksacc, tlast, c01,
                        out + off * ctw, nl);
     ABC_HIP_CHECK(hipGetLastError());
+  }
+  if (lanes > 1) {  // join
+    for (int l = 0; l < lanes; l++) {
+      ABC_HIP_CHECK(hipEventRecord(c->lane_join[l], c->lane[l]));
+      ABC_HIP_CHECK(hipStreamWaitEvent(c->stream, c->lane_join[l], 0));
+    }
   }
   return 0;
 }
@@ -203,19 +218,26 @@ int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
   // (one 1024-thread workgroup per CU, so a launch needs >> 256 workgroups): take the whole batch,
   // capped at 4 GiB of scratch.
   size_t chunk = 0;
+  int lanes = 2;
   if (const char *e = std::getenv("ABC_HIP_CHUNK")) chunk = (size_t)std::atol(e);
+  if (const char *e = std::getenv("ABC_HIP_LANES")) lanes = std::atoi(e) >= 2 ? 2 : 1;
   if (!chunk) {
+    // every chunk should still be several full waves of 256 workgroups; scratch capped at 4 GiB
     const size_t per_ct_bytes = fused_scratch_limbs(nl) * c->n * 8;
-    chunk = ((size_t)3 << 30) / per_ct_bytes;
+    const size_t cap = ((size_t)4 << 30) / per_ct_bytes / (size_t)lanes;
+    chunk = (count + lanes - 1) / lanes;
+    if (chunk > 256) chunk = 256;  // measured on MI355X: 256-pair chunks on two lanes beat one 512-pair chunk per lane
+    if (chunk > cap) chunk = cap;
     if (chunk < 1) chunk = 1;
   }
   if (chunk > count) chunk = count;
+  if (count <= 8) lanes = 1;
   switch (c->logn) {
-    case 10: return run_fused<10>(c, a, b, out, nl, count, chunk);
-    case 11: return run_fused<11>(c, a, b, out, nl, count, chunk);
-    case 12: return run_fused<12>(c, a, b, out, nl, count, chunk);
-    case 13: return run_fused<13>(c, a, b, out, nl, count, chunk);
-    case 14: return run_fused<14>(c, a, b, out, nl, count, chunk);
+    case 10: return run_fused<10>(c, a, b, out, nl, count, chunk, lanes);
+    case 11: return run_fused<11>(c, a, b, out, nl, count, chunk, lanes);
+    case 12: return run_fused<12>(c, a, b, out, nl, count, chunk, lanes);
+    case 13: return run_fused<13>(c, a, b, out, nl, count, chunk, lanes);
+    case 14: return run_fused<14>(c, a, b, out, nl, count, chunk, lanes);
     default: return -1;
   }
 }

@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="independent ciphertext pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="independent ciphertext pairs per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
