@@ -70,6 +70,17 @@ def _cpu_worker(primes, seconds, w):
     return ops, time.time() - t0
 
 
+def measured_traffic(batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate runs and corrected as MI355X_MICROARCH.md prescribes; profiles/r01_pmc_traffic.json), scaled to this
+    batch.  bench.py cannot collect PMC counters itself; None if the profile is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["hbm_bytes_per_mul_relin"] * batch
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -149,11 +160,12 @@ def main():
             "config": {"workload": "CKKS N=16384, 4 data limbs {50,40,40,40} + special 50-bit prime, ct x ct multiply + relinearize",
                        "batch_per_gpu": B, "sharding": "independent ciphertext pairs per rank, result gather only"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "abc_hip_mul_relin (k_fused_tensor_intt + k_fused_ks_accum + k_fused_ks_moddown)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
+                         "kernel": "abc_hip_mul_relin = k_fused_tensor_intt + k_fused_ks_decomp_ntt (dominant) + k_fused_ks_mac + "
+                                   "k_fused_ks_special_intt + k_fused_ks_moddown",
                          "algorithmic_bytes_per_launch": ALGO_BYTES * B, "launch_ms": launch_ms},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # CPU leg on rank 0 at N=1 only
             # parity spot check of the measured path against the oracle, then the CPU leg
             from oracle import oracle_py as om
             o = om.Oracle(om.CKKS, N, primes)

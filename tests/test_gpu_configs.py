@@ -1,0 +1,117 @@
+"""BASELINE.json configs 3-5 as circuits through the C ABI, checked against the CPU oracle (residues,
+bit-exact) and against the cleartext computation (decrypted values).
+
+  config 3  CKKS N=2^14, 4 limbs: dot product = mul+relin, rescale, rotate-and-add tree (the target form of the
+            reference's Vectorizer, ref:test/visitor/VectorizerTest.cpp:169-173,209-214)
+  config 4  CKKS N=2^15: 8x8 box sum on 64x64 images by separable log-tree rotations {1,2,4} then {64,128,256}
+            (layout x*64+y and omitted normalisation as ref:test/end-to-end/BoxBlurTest.cpp:16-38)
+  config 5  BFV N=2^16: depth-8 multiply chain (explicit primes; SEAL's default table stops at 2^15)
+CKKS and the N >= 2^15 cases have no reference implementation or test: parity is GPU == oracle ("parity unpinned"
+vs the reference).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(name, got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError("%s: %d/%d words differ, first at %s" % (name, len(bad), got.size, tuple(bad[0])))
+
+
+def _pair(oracle_mod, capi, scheme, n, primes, t=0, seed=0xABC00001):
+    o = oracle_mod.Oracle(scheme, n, primes, t)
+    o.keygen(seed)
+    g = capi.Context(scheme, n, primes, t)
+    g.keygen(seed)  # shared sampling spec: the device generates the identical keys
+    return o, g
+
+
+def test_config3_ckks_dot_product(oracle_mod, capi):
+    n = 16384
+    primes = oracle_mod.create_primes(n, [50, 40, 40, 40, 50])
+    o, g = _pair(oracle_mod, capi, oracle_mod.CKKS, n, primes)
+    rng = np.random.default_rng(3)
+    x, y = rng.uniform(-1, 1, n // 2), rng.uniform(-1, 1, n // 2)
+    scale = 2.0 ** 40
+    cx, cy = o.encrypt(o.ckks_encode(x, scale), 1), o.encrypt(o.ckks_encode(y, scale), 2)
+
+    def circuit(be):
+        acc = be.rescale(be.mul_relin(cx, cy))
+        step = n // 4  # 4096, 2048, ..., 1 : 13 rotations fold the 8192 slots
+        while step >= 1:
+            acc = be.add(acc, be.rotate(acc, step))
+            step //= 2
+        return acc
+
+    want, got = circuit(o), circuit(g)
+    _eq("dot product circuit", got, want)
+    val = o.ckks_decode(o.decrypt(got), scale * scale / primes[3]).real
+    assert abs(val[0] - float(np.dot(x, y))) < 1e-3  # CKKS tolerance: 8192 summands, 2^40 scale
+    assert np.abs(val - val[0]).max() < 1e-3         # every slot holds the sum
+
+
+def test_config4_ckks_box_blur_batch(oracle_mod, capi):
+    n = 32768
+    primes = oracle_mod.create_primes(n, [50, 40, 40, 50])
+    o, g = _pair(oracle_mod, capi, oracle_mod.CKKS, n, primes)
+    rng = np.random.default_rng(4)
+    imgs = rng.integers(0, 1025, size=(2, 64, 64)).astype(np.float64)  # the reference's pixel range, BoxBlurTest.cpp:123
+    scale = 2.0 ** 30
+    cts = np.stack([o.encrypt(o.ckks_encode(im.reshape(-1), scale), 10 + i) for i, im in enumerate(imgs)])
+
+    def circuit(be, ct):
+        acc = ct
+        for r in (1, 2, 4, 64, 128, 256):
+            acc = be.add(acc, be.rotate(acc, r))
+        return acc
+
+    want = np.stack([circuit(o, c) for c in cts])
+    got = circuit(g, cts)  # the whole batch in one call per op
+    _eq("box blur batch", got, want)
+    for b, im in enumerate(imgs):
+        dec = o.ckks_decode(o.decrypt(got[b]), scale).real[:4096].reshape(64, 64)
+        ref = sum(np.roll(np.roll(im, -dx, axis=0), -dy, axis=1) for dx in range(8) for dy in range(8))
+        assert np.abs(dec[:56, :56] - ref[:56, :56]).max() < 1e-2  # interior: rotations do not wrap there
+
+
+def test_config5_bfv_depth8_chain(oracle_mod, capi):
+    n = 65536
+    primes = oracle_mod.create_primes(n, [55] * 8 + [56])
+    t = oracle_mod.plain_modulus_batching(n, 20)
+    assert t == 786433
+    o, g = _pair(oracle_mod, capi, oracle_mod.BFV, n, primes, t)
+    vals = [[(3 * i + k) % 7 + 1 for i in range(16)] for k in range(9)]
+    cts = [o.encrypt(o.encode(oracle_mod.expand_vector(v, n)), 50 + k) for k, v in enumerate(vals)]
+    # residue parity on the first two levels (the oracle's BEHZ at this size takes seconds per multiply)
+    r_o = o.mul_relin(cts[0], cts[1])
+    r_g = g.mul_relin(cts[0], cts[1])
+    _eq("N=2^16 mul_relin level 1", r_g, r_o)
+    r_o2 = o.mul_relin(r_o, cts[2])
+    r_g2 = g.mul_relin(r_g, cts[2])
+    _eq("N=2^16 mul_relin level 2", r_g2, r_o2)
+    acc = r_g2
+    for k in range(3, 9):
+        acc = g.mul_relin(acc, cts[k])
+    want = [1] * 16
+    for v in vals:
+        want = [(a * b) % t for a, b in zip(want, v)]
+    dec = o.decode(o.decrypt(acc))[:16] % t
+    assert list(dec) == want
+    assert o.noise_budget(acc) > 0
+
+
+def test_bfv_default_8192_and_16384(oracle_mod, capi):
+    """The reference factory's default ring is 16384 slots (SealCiphertextFactory.h:16): 8 data limbs + special."""
+    for n in (8192, 16384):
+        o, g = _pair(oracle_mod, capi, oracle_mod.BFV, n, oracle_mod.default_bfv_primes(n), oracle_mod.plain_modulus_batching(n, 20), seed=5)
+        a = o.encrypt(o.encode(oracle_mod.expand_vector([3, 3, 1, 4, 5, 9], n)), 1)
+        b = o.encrypt(o.encode(oracle_mod.expand_vector([0, 1, 2, 1, 10, 21], n)), 2)
+        r = g.mul_relin(a, b)
+        _eq("BFVDefault(%d) mul_relin" % n, r, o.mul_relin(a, b))
+        assert list(o.decode(o.decrypt(r))[:6]) == [0, 3, 2, 4, 50, 189]
+        _eq("BFVDefault(%d) rotate" % n, g.rotate(a, 3), o.rotate(a, 3))
