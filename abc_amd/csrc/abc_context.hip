@@ -33,6 +33,19 @@ int ensure_workspace(abc_hip_ctx *c, size_t bytes) {
   return 0;
 }
 
+int ensure_aux(abc_hip_ctx *c, int which, size_t bytes) {
+  if (bytes <= c->aux_bytes[which]) return 0;
+  if (c->aux[which]) {
+    ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->aux[which]);
+    c->aux[which] = nullptr;
+    c->aux_bytes[which] = 0;
+  }
+  ABC_HIP_CHECK(hipMalloc(&c->aux[which], bytes));
+  c->aux_bytes[which] = bytes;
+  return 0;
+}
+
 static Mod make_mod(uint64_t q, int logn, bool ntt) {
   using namespace host;
   Mod m{};
@@ -242,15 +255,12 @@ static int apply_galois(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, uint32_
   if (!count) return 0;
   const size_t N = (size_t)c->n, pw = (size_t)nl * N;
   const bool ntt_form = (c->scheme == ABC_HIP_SCHEME_CKKS);
-  // g(c0), g(c1) into a private buffer (keyswitch_generic uses c->ws)
-  u64 *g = nullptr;
-  ABC_HIP_CHECK(hipMalloc(&g, count * 2 * pw * 8));
-  int rc = launch_galois(c, in, g, nl, count * 2, elt, ntt_form);
+  // g(c0), g(c1) live in arena 0 (keyswitch_generic uses c->ws)
+  if (ensure_aux(c, 0, count * 2 * pw * 8)) return 1;
+  u64 *g = (u64 *)c->aux[0];
+  if (launch_galois(c, in, g, nl, count * 2, elt, ntt_form)) return 1;
   // out = (g(c0) + ks0, ks1) with ks = KeySwitch(g(c1))
-  if (!rc) rc = keyswitch_generic(c, g + pw, 2 * pw, it->second, out, nl, count, g, 2 * pw, false);
-  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("apply_galois: sync failed"); rc = 1; }
-  (void)hipFree(g);
-  return rc;
+  return keyswitch_generic(c, g + pw, 2 * pw, it->second, out, nl, count, g, 2 * pw, false);
 }
 
 static int rotate(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, int steps, size_t count) {
@@ -261,33 +271,32 @@ static int rotate(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, int steps, si
   }
   const uint32_t elt = elt_from_step(c, steps);
   if (!elt) { set_error("step count too large"); return 1; }
+  std::vector<int> terms;
   if (c->d_galois.count(elt)) {
-    if (in != out) return apply_galois(c, in, out, nl, elt, count);
-    u64 *tmp = nullptr;
-    ABC_HIP_CHECK(hipMalloc(&tmp, bytes));
-    int rc = apply_galois(c, in, tmp, nl, elt, count);
-    if (!rc) ABC_HIP_CHECK(hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToDevice, c->stream));
-    if (!rc) ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
-    (void)hipFree(tmp);
-    return rc;
+    terms.push_back(steps);
+  } else {
+    // no key for this element: SEAL decomposes the step count in non-adjacent form (Evaluator::rotate_internal)
+    for (int s : naf(steps))
+      if ((size_t)std::abs(s) != ((size_t)c->n >> 1)) terms.push_back(s);
+    if (naf(steps).size() == 1) { set_error("Galois key not present"); return 1; }
+    for (int s : terms)
+      if (!c->d_galois.count(elt_from_step(c, s))) { set_error("Galois key not present"); return 1; }
   }
-  const std::vector<int> terms = naf(steps);
-  if (terms.size() == 1) { set_error("Galois key not present"); return 1; }
-  u64 *bufA = nullptr, *bufB = nullptr;
-  ABC_HIP_CHECK(hipMalloc(&bufA, bytes));
-  ABC_HIP_CHECK(hipMalloc(&bufB, bytes));
-  ABC_HIP_CHECK(hipMemcpyAsync(bufA, in, bytes, hipMemcpyDeviceToDevice, c->stream));
-  int rc = 0;
-  for (int s : terms) {
-    if ((size_t)std::abs(s) == ((size_t)c->n >> 1)) continue;
-    rc = rotate(c, bufA, bufB, nl, s, count);
-    if (rc) break;
-    std::swap(bufA, bufB);
+  // apply_galois is out of place: ping-pong through arenas 1 and 2, last hop lands in `out`
+  const u64 *cur = in;
+  for (size_t i = 0; i < terms.size(); i++) {
+    const bool last = (i + 1 == terms.size());
+    u64 *dst = out;
+    if (!last || out == cur) {
+      const int which = 1 + (int)(i & 1);
+      if (ensure_aux(c, which, bytes)) return 1;
+      dst = (u64 *)c->aux[which];
+    }
+    if (apply_galois(c, cur, dst, nl, elt_from_step(c, terms[i]), count)) return 1;
+    cur = dst;
   }
-  if (!rc) ABC_HIP_CHECK(hipMemcpyAsync(out, bufA, bytes, hipMemcpyDeviceToDevice, c->stream));
-  if (!rc) ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
-  (void)hipFree(bufA); (void)hipFree(bufB);
-  return rc;
+  if (cur != out) ABC_HIP_CHECK(hipMemcpyAsync(out, cur, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
 }
 
 static int relinearize(abc_hip_ctx *c, const u64 *ct3, u64 *out2, int nl, size_t count) {
@@ -432,6 +441,7 @@ void abc_hip_ctx_destroy(abc_hip_ctx *c) {
   (void)hipFree(c->d_sk); (void)hipFree(c->d_pk); (void)hipFree(c->d_relin);
   for (auto &kv : c->d_galois) (void)hipFree(kv.second);
   (void)hipFree(c->ws);
+  for (void *p : c->aux) (void)hipFree(p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->lane_fork) (void)hipEventDestroy(c->lane_fork);
@@ -594,14 +604,12 @@ int abc_hip_mul_relin(abc_hip_ctx *c, const uint64_t *a, const uint64_t *b, uint
     const int rc = ckks_mul_relin_fused(c, a, b, out, nl, count);
     if (rc >= 0) return rc;
   }
-  // generic path: size-3 product in a private buffer, then key switch
-  u64 *t3 = nullptr;
+  // generic path: size-3 product in arena 1, then key switch
   const size_t bytes = count * 3 * nl * (size_t)c->n * 8;
-  ABC_HIP_CHECK(hipMalloc(&t3, bytes ? bytes : 8));
+  if (ensure_aux(c, 1, bytes ? bytes : 8)) return 1;
+  u64 *t3 = (u64 *)c->aux[1];
   int rc = (c->scheme == ABC_HIP_SCHEME_CKKS) ? launch_ckks_tensor(c, a, b, t3, nl, count) : bfv_multiply(c, a, b, t3, count);
   if (!rc) rc = relinearize(c, t3, out, nl, count);
-  if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("mul_relin: sync failed"); rc = 1; }
-  (void)hipFree(t3);
   return rc;
 }
 int abc_hip_rotate(abc_hip_ctx *c, const uint64_t *in, uint64_t *out, int nl, int steps, size_t count) {

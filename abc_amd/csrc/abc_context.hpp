@@ -90,9 +90,12 @@ struct abc_hip_ctx {
   uint64_t *d_sk = nullptr, *d_pk = nullptr, *d_relin = nullptr;
   std::map<uint32_t, uint64_t *> d_galois;
   std::vector<uint32_t> galois_order;
-  // workspace
+  // workspace (kernel-sequence scratch) and three caller-level arenas (products, rotation ping-pong buffers);
+  // all grow on demand and are reused, so steady-state calls perform no hipMalloc / hipFree
   void *ws = nullptr;
   size_t ws_bytes = 0;
+  void *aux[3] = {nullptr, nullptr, nullptr};
+  size_t aux_bytes[3] = {0, 0, 0};
   size_t limb_words() const { return (size_t)n; }
   size_t key_words() const { return (size_t)L * 2 * K * n; }
 };
@@ -111,6 +114,7 @@ void set_error(const std::string &msg);
 
 // workspace: grows on demand (never inside a timed region after warm-up)
 int ensure_workspace(abc_hip_ctx *c, size_t bytes);
+int ensure_aux(abc_hip_ctx *c, int which, size_t bytes);
 
 // ---- launchers implemented in the kernel translation units ----
 LimbMap key_limb_map(const abc_hip_ctx *c, int nl);  // 0..nl-1 -> data primes, nl -> special prime
