@@ -30,6 +30,7 @@ SYMBOLS = [
     "abc_hip_rotate", "abc_hip_apply_galois", "abc_hip_multiply_plain", "abc_hip_add_plain", "abc_hip_sub_plain",
     "abc_hip_rescale", "abc_hip_mod_switch", "abc_hip_ntt_forward", "abc_hip_ntt_inverse", "abc_hip_keyswitch",
     "abc_hip_microbench", "abc_hip_timer_start", "abc_hip_timer_stop",
+    "abc_hip_graph_begin", "abc_hip_graph_end", "abc_hip_graph_launch", "abc_hip_graph_destroy",
 ]
 
 
@@ -348,6 +349,21 @@ class Context:
         r = self.download(out, shp)
         cb.free(); out.free()
         return r if np.ndim(ct) == 4 else r[0]
+
+    # ---- HIP-graph capture of an op sequence ----
+    def graph_begin(self):
+        _chk(lib().abc_hip_graph_begin(self.h))
+
+    def graph_end(self):
+        g = C.c_void_p()
+        _chk(lib().abc_hip_graph_end(self.h, C.byref(g)))
+        return g
+
+    def graph_launch(self, g):
+        _chk(lib().abc_hip_graph_launch(self.h, g))
+
+    def graph_destroy(self, g):
+        _chk(lib().abc_hip_graph_destroy(self.h, g))
 
     def microbench(self, which, iters):
         ms = C.c_double()

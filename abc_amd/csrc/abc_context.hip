@@ -19,8 +19,15 @@ namespace abc {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
+static bool capturing(abc_hip_ctx *c) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(c->stream, &st) != hipSuccess) return false;
+  return st != hipStreamCaptureStatusNone;
+}
+
 int ensure_workspace(abc_hip_ctx *c, size_t bytes) {
   if (bytes <= c->ws_bytes) return 0;
+  if (capturing(c)) { set_error("scratch would grow during graph capture: run the sequence once eagerly first"); return 1; }
   if (c->ws) {
     ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
     (void)hipFree(c->ws);
@@ -35,6 +42,7 @@ int ensure_workspace(abc_hip_ctx *c, size_t bytes) {
 
 int ensure_aux(abc_hip_ctx *c, int which, size_t bytes) {
   if (bytes <= c->aux_bytes[which]) return 0;
+  if (capturing(c)) { set_error("scratch would grow during graph capture: run the sequence once eagerly first"); return 1; }
   if (c->aux[which]) {
     ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
     (void)hipFree(c->aux[which]);
@@ -419,6 +427,11 @@ int abc_hip_ctx_create(int scheme, int logn, const uint64_t *primes, int nprimes
   } catch (const std::exception &e) {
     set_error(e.what());
   }
+  if (!rc && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    rc = 1;
+  }
+  if (!rc) c->stream = c->own_stream;  // operations run on a private stream unless abc_hip_set_stream overrides it
   if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
               hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming) != hipSuccess ||
               hipEventCreateWithFlags(&c->lane_join[0], hipEventDisableTiming) != hipSuccess ||
@@ -442,6 +455,7 @@ void abc_hip_ctx_destroy(abc_hip_ctx *c) {
   for (auto &kv : c->d_galois) (void)hipFree(kv.second);
   (void)hipFree(c->ws);
   for (void *p : c->aux) (void)hipFree(p);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->lane_fork) (void)hipEventDestroy(c->lane_fork);
@@ -467,7 +481,8 @@ int abc_hip_ctx_info(const abc_hip_ctx *c, int what) {
 
 int abc_hip_set_stream(abc_hip_ctx *c, void *stream) {
   CTX_GUARD(c);
-  c->stream = (hipStream_t)stream;
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->stream = stream ? (hipStream_t)stream : c->own_stream;  // NULL selects the context's private stream again
   return 0;
 }
 int abc_hip_sync(abc_hip_ctx *c) {
@@ -688,6 +703,36 @@ int abc_hip_keyswitch(abc_hip_ctx *c, const uint64_t *target, uint32_t key_kind,
   else if (c->d_galois.count(key_kind)) key = c->d_galois[key_kind];
   if (!key) { set_error("keyswitch: key not present"); return 1; }
   return keyswitch_generic(c, target, (size_t)nl * c->n, key, out2, nl, count, nullptr, 0, false);
+}
+
+// ---- graph capture ----
+int abc_hip_graph_begin(abc_hip_ctx *c) {
+  CTX_GUARD(c);
+  if (!c->stream) { set_error("graph capture needs an explicit stream: call abc_hip_set_stream with a non-default stream"); return 1; }
+  ABC_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+int abc_hip_graph_end(abc_hip_ctx *c, void **out) {
+  CTX_GUARD(c);
+  hipGraph_t graph = nullptr;
+  ABC_HIP_CHECK(hipStreamEndCapture(c->stream, &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); return 1; }
+  *out = exec;
+  return 0;
+}
+int abc_hip_graph_launch(abc_hip_ctx *c, void *exec) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)exec, c->stream));
+  return 0;
+}
+int abc_hip_graph_destroy(abc_hip_ctx *c, void *exec) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  ABC_HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)exec));
+  return 0;
 }
 
 int abc_hip_microbench(abc_hip_ctx *c, int which, int iters, double *ms) { CTX_GUARD(c); return microbench(c, which, iters, ms); }

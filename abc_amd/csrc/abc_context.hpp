@@ -71,7 +71,8 @@ struct abc_hip_ctx {
   int scheme = 0, logn = 0, n = 0, K = 0, L = 0, device = 0;
   std::vector<uint64_t> primes;  // key-level chain: data limbs + special
   uint64_t t = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // stream every operation is enqueued on
+  hipStream_t own_stream = nullptr;  // the context's private stream (default)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // two internal lanes let an HBM-streaming kernel of one chunk overlap an ALU-bound transform of another
   hipStream_t lane[2] = {nullptr, nullptr};

@@ -118,6 +118,16 @@ int abc_hip_sub_plain(abc_hip_ctx *ctx, const uint64_t *d_ct, const uint64_t *d_
 int abc_hip_rescale(abc_hip_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int size, int nl, size_t count);
 int abc_hip_mod_switch(abc_hip_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int size, int nl, size_t count);
 
+/* ---- HIP-graph capture of an operation sequence (a recorded circuit in place of the
+ * eager per-call dispatch of SpecialRuntimeVisitor, src/runtime/RuntimeVisitor.cpp:40-159).
+ * Everything enqueued on the context between begin and end is recorded instead of executed; the sequence must have
+ * run once eagerly before (so that no scratch allocation happens while capturing) and may only use device pointers
+ * that stay valid for every launch.  abc_hip_encrypt / abc_hip_keygen / *_h2d / *_d2h are not capturable. */
+int abc_hip_graph_begin(abc_hip_ctx *ctx);
+int abc_hip_graph_end(abc_hip_ctx *ctx, void **graph_exec_out);
+int abc_hip_graph_launch(abc_hip_ctx *ctx, void *graph_exec);
+int abc_hip_graph_destroy(abc_hip_ctx *ctx, void *graph_exec);
+
 /* ---- raw transforms, exposed for kernel-level parity tests and profiling ---- */
 /* mod_kind: 0 = key-level prime `index`, 1 = BEHZ Bsk prime `index`, 2 = plaintext modulus */
 int abc_hip_ntt_forward(abc_hip_ctx *ctx, uint64_t *d_data, int mod_kind, int index, size_t count);
