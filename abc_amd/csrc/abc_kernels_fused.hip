@@ -58,7 +58,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_intt(DevCtx c, 
 
 // K2a: one workgroup per (ct, key prime I, decomposition limb J != I): residues of c2_J modulo key prime I,
 // transformed in LDS -> dec[ct][I][J]
-template <int LB>
+template <int LB, bool GUARD>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_decomp_ntt(DevCtx c, const u64 *__restrict__ c2coef,
                                                                         u64 *__restrict__ dec, int nl) {
   __shared__ u64 lds[lds_words(LB)];
@@ -73,9 +73,9 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_decomp_ntt(DevCtx c
   const u64 *__restrict__ src = c2coef + (ct * nl + J) * N;
   u64 *__restrict__ dst = dec + ((ct * (nl + 1) + I) * nl + J) * N;
   const bool need_reduce = c.mods[J].q > m.q;  // values are < q_J already
-  ntt_fwd_block<LB>(
+  ntt_fwd_block<LB, GUARD>(
       lds, [&](int, int i) { const u64 v = src[i]; return need_reduce ? reduce64(v, m) : v; },
-      [&](int, int i, u64 v) { dst[i] = canon4(v, m); }, t, m, 0, 0);
+      [&](int, int i, u64 v) { dst[i] = canon_fwd<GUARD>(v, m); }, t, m, 0, 0);
 }
 
 // K2b: streaming inner product with the key: acc_comp[k] = sum_J x_J[k] * key[J][comp][I][k]
@@ -132,7 +132,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_special_intt(DevCtx
       0, 0);
 }
 
-template <int LB>
+template <int LB, bool GUARD>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown(DevCtx c, const u64 *__restrict__ ksacc,
                                                                      const u64 *__restrict__ tlast, const u64 *__restrict__ c01,
                                                                      u64 *__restrict__ out, int nl) {
@@ -150,10 +150,10 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown(DevCtx c, c
   const u64 *__restrict__ ks = ksacc + (cc * nl + j) * N;
   const u64 *__restrict__ cin = c01 + (cc * nl + j) * N;
   u64 *__restrict__ o = out + (cc * nl + j) * N;
-  ntt_fwd_block<LB>(
+  ntt_fwd_block<LB, GUARD>(
       lds, [&](int, int i) { return add_mod(reduce64(src[i], m), fix, m.q); },
       [&](int, int i, u64 v) {
-        const u64 x = canon4(v, m);
+        const u64 x = canon_fwd<GUARD>(v, m);
         o[i] = add_mod(mul_shoup(sub_mod(ks[i], x, m.q), inv, inv_s, m.q), cin[i], m.q);
       },
       t, m, 0, 0);
@@ -174,6 +174,8 @@ static int run_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int n
   const size_t per_ct = fused_scratch_limbs(nl) * N;
   if (ensure_workspace(c, (size_t)lanes * chunk * per_ct * 8)) return 1;
   const dim3 block((1 << LB) / 16);
+  bool guard = false;  // unguarded butterflies need (2 logN + 4) q < 2^64 for every key-level prime
+  for (int j = 0; j < c->K; j++) guard = guard || !unguarded_ok(c->h_mods[j].bits);
   if (lanes > 1) {  // fork: the lanes start after everything already queued on the caller's stream
     ABC_HIP_CHECK(hipEventRecord(c->lane_fork, c->stream));
     for (int l = 0; l < lanes; l++) ABC_HIP_CHECK(hipStreamWaitEvent(c->lane[l], c->lane_fork, 0));
@@ -191,12 +193,19 @@ static int run_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int n
     const size_t ctw = 2 * (size_t)nl * N;
     hipLaunchKernelGGL(k_fused_tensor_intt<LB>, dim3((unsigned)(cc * nl)), block, 0, st, c->dc, a + off * ctw, b + off * ctw, c01,
                        c2coef, c2ntt, nl);
-    hipLaunchKernelGGL(k_fused_ks_decomp_ntt<LB>, dim3((unsigned)(cc * (nl + 1) * nl)), block, 0, st, c->dc, c2coef, dec, nl);
+    if (guard)
+      hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, true>), dim3((unsigned)(cc * (nl + 1) * nl)), block, 0, st, c->dc, c2coef, dec, nl);
+    else
+      hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, false>), dim3((unsigned)(cc * (nl + 1) * nl)), block, 0, st, c->dc, c2coef, dec, nl);
     hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, dec, c2ntt,
                        c->d_relin, ksacc, tsp, nl, cc);
     hipLaunchKernelGGL(k_fused_ks_special_intt<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, tsp, tlast);
-    hipLaunchKernelGGL(k_fused_ks_moddown<LB>, dim3((unsigned)(cc * 2 * nl)), block, 0, st, c->dc, ksacc, tlast, c01,
-                       out + off * ctw, nl);
+    if (guard)
+      hipLaunchKernelGGL((k_fused_ks_moddown<LB, true>), dim3((unsigned)(cc * 2 * nl)), block, 0, st, c->dc, ksacc, tlast, c01,
+                         out + off * ctw, nl);
+    else
+      hipLaunchKernelGGL((k_fused_ks_moddown<LB, false>), dim3((unsigned)(cc * 2 * nl)), block, 0, st, c->dc, ksacc, tlast, c01,
+                         out + off * ctw, nl);
     ABC_HIP_CHECK(hipGetLastError());
   }
   if (lanes > 1) {  // join

@@ -10,7 +10,7 @@
 
 namespace abc {
 
-template <int LB>
+template <int LB, bool GUARD>
 __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data, LimbMap map, int nl, int S0) {
   __shared__ u64 lds[lds_words(LB)];
   const size_t limb = blockIdx.x >> S0;
@@ -19,8 +19,8 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data,
   const Mod m = c.mods[mid];
   const NttTable t = ntt_table(c, mid);
   u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
-  ntt_fwd_block<LB>(
-      lds, [&](int, int i) { return base[i]; }, [&](int, int i, u64 v) { base[i] = canon4(v, m); }, t, m, S0, b);
+  ntt_fwd_block<LB, GUARD>(
+      lds, [&](int, int i) { return base[i]; }, [&](int, int i, u64 v) { base[i] = canon_fwd<GUARD>(v, m); }, t, m, S0, b);
 }
 
 template <int LB>
@@ -107,8 +107,14 @@ constexpr int kBigBlockLB = 12;  // LDS block size used under the strided pass f
 template <int LB>
 static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, int S0, bool fwd) {
   dim3 grid((unsigned)(total_limbs << S0)), block((1 << LB) / 16);
-  if (fwd)
-    hipLaunchKernelGGL(k_ntt_fwd<LB>, grid, block, 0, c->stream, c->dc, d, map, nl, S0);
+  // every limb of the launch must allow the unguarded butterflies; the strided pre-pass (S0 > 0) already
+  // spent part of the headroom, keep the guard there
+  bool guard = (S0 != 0);
+  for (int j = 0; j < nl; j++) guard = guard || !unguarded_ok(c->h_mods[map.id[j]].bits);
+  if (fwd && guard)
+    hipLaunchKernelGGL((k_ntt_fwd<LB, true>), grid, block, 0, c->stream, c->dc, d, map, nl, S0);
+  else if (fwd)
+    hipLaunchKernelGGL((k_ntt_fwd<LB, false>), grid, block, 0, c->stream, c->dc, d, map, nl, S0);
   else
     hipLaunchKernelGGL(k_ntt_inv<LB>, grid, block, 0, c->stream, c->dc, d, map, nl, S0);
   ABC_HIP_CHECK(hipGetLastError());

@@ -91,10 +91,25 @@ __device__ __forceinline__ u64 add_mod(u64 a, u64 b, u64 q) {
 __device__ __forceinline__ u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
 __device__ __forceinline__ u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
 
+// x - c if that does not borrow, else x  (sub + carry-select: no separate 64-bit compare)
+__device__ __forceinline__ u64 csub(u64 x, u64 c) {
+  unsigned long t;
+  const bool borrow = __builtin_usubl_overflow((unsigned long)x, (unsigned long)c, &t);
+  return borrow ? x : (u64)t;
+}
+
 // Shoup multiplication by a constant w with ws = floor(w * 2^64 / q): result in [0, 2q) for ANY y.
+// y*w - h*q is evaluated as y*w + h*(2^64 - q) so that both low products chain through v_mad_u64_u32's
+// 64-bit addend (2 mad + 4 mul_lo + 2 add3) instead of two products and a 64-bit subtract.
 __device__ __forceinline__ u64 mul_shoup_lazy(u64 y, u64 w, u64 ws, u64 q) {
-  u64 h = mulhi64(y, ws);
-  return y * w - h * q;
+  const u64 h = mulhi64(y, ws);
+  const u64 nq = 0 - q;
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
+  const u32 h0 = (u32)h, h1 = (u32)(h >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+  u64 acc = (u64)y0 * w0;
+  acc = (u64)h0 * n0 + acc;
+  const u32 hi = (u32)(acc >> 32) + y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
+  return ((u64)hi << 32) | (u32)acc;
 }
 __device__ __forceinline__ u64 mul_shoup(u64 y, u64 w, u64 ws, u64 q) {
   u64 r = mul_shoup_lazy(y, w, ws, q);

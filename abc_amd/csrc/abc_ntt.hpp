@@ -34,7 +34,11 @@ struct NttTable {
 
 // ---- one radix-2^R register pass over NG = 16>>R groups -------------------------------------------
 // Forward (CT): stages S..S+R-1 of the block-local transform.
-template <int LB, int S, int R, bool UNIFORM>
+// GUARD = false: no per-stage correction of X; every stage adds at most 2q to a value, so after all
+// logN stages a canonical input stays below (2 logN + 1) q -- usable whenever that fits 64 bits (q < 2^58
+// for N <= 2^16), which holds for every SEAL default prime up to N = 16384 and for the CKKS chains here; only
+// the 61-bit BEHZ primes (and 59/60-bit user primes) take the guarded form.
+template <int LB, int S, int R, bool UNIFORM, bool GUARD = true>
 __device__ __forceinline__ void fwd_pass(u64 (&x)[16], const int (&hi)[16 >> R], const NttTable &t, u64 q, u64 two_q,
                                          int S0, int b) {
   constexpr int NG = 16 >> R;
@@ -53,7 +57,7 @@ __device__ __forceinline__ void fwd_pass(u64 (&x)[16], const int (&hi)[16 >> R],
         u64 w = t.tw[idx], ws = t.tws[idx];
         u64 &X = x[g * (1 << R) + k];
         u64 &Y = x[g * (1 << R) + (k | half)];
-        u64 a = X >= two_q ? X - two_q : X;
+        u64 a = GUARD ? csub(X, two_q) : X;
         u64 v = mul_shoup_lazy(Y, w, ws, q);
         X = a + v;
         Y = a + two_q - v;
@@ -82,8 +86,7 @@ __device__ __forceinline__ void inv_pass(u64 (&x)[16], const int (&hi)[16 >> R],
         u64 &X = x[g * (1 << R) + k];
         u64 &Y = x[g * (1 << R) + (k | half)];
         u64 a = X, c = Y;
-        u64 s = a + c;
-        X = s >= two_q ? s - two_q : s;
+        X = csub(a + c, two_q);
         Y = mul_shoup_lazy(a + two_q - c, w, ws, q);
       }
     }
@@ -147,7 +150,7 @@ struct NoHook {
 
 // `before_last` runs right before the final register pass (after its barrier): the place to issue the
 // global loads of a persistent workgroup's NEXT limb, so their latency hides under the last pass and the stores.
-template <int LB, class Load, class Store, class Hook = NoHook>
+template <int LB, bool GUARD = true, class Load, class Store, class Hook = NoHook>
 __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
                                               int b, Hook before_last = Hook()) {
   using SC = Sched<LB>;
@@ -163,7 +166,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
-    fwd_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
   }
   __syncthreads();
@@ -173,7 +176,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     int hi[P::NG], lo[P::NG];
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
-    fwd_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
     if constexpr (SC::R3 == 0 && SC::R2 == 0) {
 #pragma unroll
       for (int g = 0; g < P::NG; g++)
@@ -192,7 +195,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     P::groups(tid, hi, lo);
     if constexpr (SC::R3 == 0) before_last();
     lds_load<LB, S, R>(lds, x, hi, lo);
-    fwd_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
     if constexpr (SC::R3 == 0) {
 #pragma unroll
       for (int g = 0; g < P::NG; g++)
@@ -211,7 +214,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     P::groups(tid, hi, lo);
     before_last();
     lds_load<LB, S, R>(lds, x, hi, lo);
-    fwd_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
 #pragma unroll
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
@@ -302,11 +305,18 @@ __device__ __forceinline__ int last_fwd_elem(int r) {
 }
 
 // lazily reduced [0,4q) -> [0,q)
-__device__ __forceinline__ u64 canon4(u64 v, const Mod &m) {
-  if (v >= m.two_q) v -= m.two_q;
-  if (v >= m.q) v -= m.q;
-  return v;
+__device__ __forceinline__ u64 canon4(u64 v, const Mod &m) { return csub(csub(v, m.two_q), m.q); }
+// output of an unguarded forward transform, [0,32q) -> [0,q)
+__device__ __forceinline__ u64 canon32(u64 v, const Mod &m) {
+  v = csub(v, m.two_q << 3);
+  v = csub(v, m.two_q << 2);
+  v = csub(v, m.two_q << 1);
+  return canon4(v, m);
 }
+template <bool GUARD>
+__device__ __forceinline__ u64 canon_fwd(u64 v, const Mod &m) { return GUARD ? canon4(v, m) : canon32(v, m); }
+// a modulus may skip the per-stage guard when (2 logN + 4) q < 2^64
+__host__ __device__ __forceinline__ bool unguarded_ok(u32 bits) { return bits <= 58; }
 // scale by N^-1 and canonicalise (input [0,2q) or any 64-bit value)
 __device__ __forceinline__ u64 scale_inv_n(u64 v, const Mod &m) { return mul_shoup(v, m.inv_n, m.inv_n_s, m.q); }
 
