@@ -257,6 +257,14 @@ static std::vector<int> naf(int value) {
   return out;
 }
 
+// key switch dispatcher: LDS-resident kernels when the ring fits, generic kernels otherwise
+static int keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out2, int nl, size_t count,
+                     const u64 *addend, size_t addend_stride, bool add_c1) {
+  const int rc = keyswitch_fused(c, target, target_stride, key, out2, nl, count, addend, addend_stride, add_c1);
+  if (rc >= 0) return rc;
+  return keyswitch_generic(c, target, target_stride, key, out2, nl, count, addend, addend_stride, add_c1);
+}
+
 static int apply_galois(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, uint32_t elt, size_t count) {
   auto it = c->d_galois.find(elt);
   if (it == c->d_galois.end()) { set_error("Galois key not present"); return 1; }
@@ -268,7 +276,7 @@ static int apply_galois(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, uint32_
   u64 *g = (u64 *)c->aux[0];
   if (launch_galois(c, in, g, nl, count * 2, elt, ntt_form)) return 1;
   // out = (g(c0) + ks0, ks1) with ks = KeySwitch(g(c1))
-  return keyswitch_generic(c, g + pw, 2 * pw, it->second, out, nl, count, g, 2 * pw, false);
+  return keyswitch(c, g + pw, 2 * pw, it->second, out, nl, count, g, 2 * pw, false);
 }
 
 static int rotate(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, int steps, size_t count) {
@@ -311,7 +319,7 @@ static int relinearize(abc_hip_ctx *c, const u64 *ct3, u64 *out2, int nl, size_t
   if (!c->d_relin) { set_error("relinearize: no relinearisation key"); return 1; }
   const size_t pw = (size_t)nl * c->n;
   // target = c2 (poly 2 of each size-3 ciphertext); addend = (c0, c1)
-  return keyswitch_generic(c, ct3 + 2 * pw, 3 * pw, c->d_relin, out2, nl, count, ct3, 3 * pw, true);
+  return keyswitch(c, ct3 + 2 * pw, 3 * pw, c->d_relin, out2, nl, count, ct3, 3 * pw, true);
 }
 
 }  // namespace abc
@@ -702,7 +710,7 @@ int abc_hip_keyswitch(abc_hip_ctx *c, const uint64_t *target, uint32_t key_kind,
   if (key_kind == 0) key = c->d_relin;
   else if (c->d_galois.count(key_kind)) key = c->d_galois[key_kind];
   if (!key) { set_error("keyswitch: key not present"); return 1; }
-  return keyswitch_generic(c, target, (size_t)nl * c->n, key, out2, nl, count, nullptr, 0, false);
+  return keyswitch(c, target, (size_t)nl * c->n, key, out2, nl, count, nullptr, 0, false);
 }
 
 // ---- graph capture ----

@@ -1,32 +1,40 @@
-// abc_kernels_fused.hip -- the hot path: CKKS ciphertext x ciphertext multiply + relinearise in five
-// launches (N <= 2^14, one workgroup per RNS limb, the limb resident in LDS).
+// abc_kernels_fused.hip -- the hot path for N <= 2^14 (one workgroup per RNS limb, the limb resident in LDS):
+// hybrid key switching for relinearisation and Galois rotations (BFV and CKKS) and the CKKS
+// ciphertext x ciphertext multiply + relinearise front end.
 //
-// Replaces SealCiphertext::multiply / multiplyInplace = Evaluator::multiply + relinearize_inplace
-// (src/runtime/SealCiphertext.cpp:102-107,121-124) for the CKKS scheme north_star names.
-//   K1 tensor_intt : c0 = a0b0, c1 = a0b1 + a1b0 written to scratch (so `out` may alias an operand); c2 = a1b1 kept in NTT form and,
-//                    through an in-LDS inverse transform, in coefficient form (key-switch operand).
-//   K2a decomp_ntt : workgroup (ct, I, J) reduces c2_J modulo key prime I and transforms it in LDS.
-//   K2b mac        : streaming inner product with relin_key[J][.][I] (128-bit lazy accumulation).
-//   K2c special    : the special-prime limb goes back to coefficients, plus the q_sp/2 rounding offset.
-//                    (A single-kernel accumulate-in-registers form of K2a+K2b was measured first: 64 VGPRs
-//                    of accumulators beside a 16-coefficient-per-lane transform exceed the 128-VGPR budget
-//                    of a 1024-thread workgroup and spill; see DESIGN.md "Key switch: what was tried".)
-//   K3 ks_moddown  : workgroup (ct, comp, j) reduces the special-prime polynomial modulo q_j, transforms
-//                    it, subtracts, scales by q_sp^-1 and adds c0 / c1.
-// Algorithmic HBM bytes per multiply: 8N(6L + 2L(L+1)); scratch per ciphertext:
-// (6L+2) limbs.
+// Replaces, for rings that fit LDS:
+//   SealCiphertext::multiply / multiplyInplace = Evaluator::multiply + relinearize_inplace
+//       (src/runtime/SealCiphertext.cpp:102-107,121-124)                     -> ckks_mul_relin_fused, keyswitch_fused
+//   SealCiphertext::rotateRows / rotateRowsInplace = Evaluator::rotate_rows    (:52-61) -> keyswitch_fused
+// Launch sequence of a multiply + relinearise (CKKS):
+//   K1  tensor_intt : c0 = a0b0, c1 = a0b1 + a1b0 to scratch (so `out` may alias an operand); c2 = a1b1 kept in
+//                     NTT form and, through an in-LDS inverse transform, in coefficient form (key-switch operand).
+//   K2a decomp_ntt  : workgroup (ct, key prime I, limb J) reduces operand limb J modulo key prime I and transforms
+//                     it in LDS.
+//   K2b mac         : streaming inner product with key[J][.][I] (128-bit lazy accumulation).
+//   K2c special     : the special-prime limb goes back to coefficients, plus the q_sp/2 rounding offset.
+//   K3  moddown     : workgroup (ct, comp, j): CKKS: reduce the special-prime polynomial modulo q_j, transform it,
+//                     subtract, scale by q_sp^-1, add c0 / c1.  BFV: inverse-transform the accumulated limb, then the
+//                     same subtract / scale / add in coefficient form.
+// (A single-kernel accumulate-in-registers form of K2a+K2b was measured first: 64 VGPRs of accumulators beside a
+// 16-coefficient-per-lane transform exceed the 128-VGPR budget of a 1024-thread workgroup and spill; DESIGN.md
+// "Key switch: what was tried".)
+// Algorithmic HBM bytes per multiply: 8N(6L + 2L(L+1)).
 #include <cstdlib>
 
 #include "abc_context.hpp"
 
 namespace abc {
 
-// slot r = 4g+k of the transforms' final register layout  <->  element 4*(tid + T*g) + k
-template <int LB>
-__device__ __forceinline__ int slot_elem(int r) {
-  return ((threadIdx.x + ((1 << LB) / 16) * (r >> 2)) << 2) + (r & 3);
+static inline unsigned stream_grid(size_t items, int block) {
+  size_t g = (items + block - 1) / block;
+  const size_t cap = 256 * 8 * 4;
+  return (unsigned)(g < cap ? (g ? g : 1) : cap);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K1 (CKKS multiply front end)
+// ---------------------------------------------------------------------------------------------------------------
 template <int LB>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_intt(DevCtx c, const u64 *__restrict__ a,
                                                                       const u64 *__restrict__ b, u64 *__restrict__ c01,
@@ -56,31 +64,51 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_intt(DevCtx c, 
       [&](int, int i, u64 v) { dcoef[i] = scale_inv_n(v, m); }, t, m, 0, 0);
 }
 
-// K2a: one workgroup per (ct, key prime I, decomposition limb J != I): residues of c2_J modulo key prime I,
-// transformed in LDS -> dec[ct][I][J]
+// inverse transform of the key-switch operand when it arrives in NTT form (CKKS rotations):
+// src limb (ct, j) at src + ct*src_stride + j*N  ->  dst[ct][j]
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_intt(DevCtx c, const u64 *__restrict__ src, size_t src_stride,
+                                                                       u64 *__restrict__ dst, int nl) {
+  __shared__ u64 lds[lds_words(LB)];
+  const size_t N = (size_t)1 << LB;
+  const int j = blockIdx.x % nl;
+  const size_t ct = blockIdx.x / nl;
+  const Mod m = c.mods[j];
+  const NttTable t = ntt_table(c, j);
+  const u64 *__restrict__ s = src + ct * src_stride + (size_t)j * N;
+  u64 *__restrict__ d = dst + (size_t)blockIdx.x * N;
+  ntt_inv_block<LB>(
+      lds, [&](int, int i) { return s[i]; }, [&](int, int i, u64 v) { d[i] = scale_inv_n(v, m); }, t, m, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// key switch: operand in coefficient form at coef + ct*coef_stride + J*N; CKKS additionally has the operand's own
+// NTT form at ntt + ct*ntt_stride + J*N (used where q_J is the key prime: switch_key_inplace, CKKS branch)
+// ---------------------------------------------------------------------------------------------------------------
+// K2a: dec[ct][I][J] = NTT_I( operand_J mod q_I )
 template <int LB, bool GUARD>
-__global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_decomp_ntt(DevCtx c, const u64 *__restrict__ c2coef,
-                                                                        u64 *__restrict__ dec, int nl) {
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_decomp_ntt(DevCtx c, const u64 *__restrict__ coef, size_t coef_stride,
+                                                                        u64 *__restrict__ dec, int nl, int skip_diagonal) {
   __shared__ u64 lds[lds_words(LB)];
   const int J = blockIdx.x % nl;
   const int I = (blockIdx.x / nl) % (nl + 1);
   const size_t ct = blockIdx.x / ((size_t)nl * (nl + 1));
-  if (J == I) return;  // q_J is the key prime itself: the NTT-form limb is used directly (CKKS branch)
+  if (skip_diagonal && J == I) return;
   const size_t N = (size_t)1 << LB;
   const int ki = (I == nl) ? c.K - 1 : I;
   const Mod m = c.mods[ki];
   const NttTable t = ntt_table(c, ki);
-  const u64 *__restrict__ src = c2coef + (ct * nl + J) * N;
+  const u64 *__restrict__ src = coef + ct * coef_stride + (size_t)J * N;
   u64 *__restrict__ dst = dec + ((ct * (nl + 1) + I) * nl + J) * N;
-  const bool need_reduce = c.mods[J].q > m.q;  // values are < q_J already
+  const bool need_reduce = c.mods[J].q > m.q;  // residues are < q_J already
   ntt_fwd_block<LB, GUARD>(
       lds, [&](int, int i) { const u64 v = src[i]; return need_reduce ? reduce64(v, m) : v; },
       [&](int, int i, u64 v) { dst[i] = canon_fwd<GUARD>(v, m); }, t, m, 0, 0);
 }
 
-// K2b: streaming inner product with the key: acc_comp[k] = sum_J x_J[k] * key[J][comp][I][k]
-__global__ __launch_bounds__(256) void k_fused_ks_mac(DevCtx c, const u64 *__restrict__ dec, const u64 *__restrict__ c2ntt,
-                                                      const u64 *__restrict__ key, u64 *__restrict__ ksacc,
+// K2b: acc_comp[k] = sum_J x_J[k] * key[J][comp][I][k]; data primes -> ksacc[ct][comp][I], special -> tsp[ct][comp]
+__global__ __launch_bounds__(256) void k_fused_ks_mac(DevCtx c, const u64 *__restrict__ dec, const u64 *__restrict__ ntt,
+                                                      size_t ntt_stride, const u64 *__restrict__ key, u64 *__restrict__ ksacc,
                                                       u64 *__restrict__ tsp, int nl, size_t count) {
   const size_t N = (size_t)c.n;
   const size_t per_ct = (size_t)(nl + 1) * (N / 2);
@@ -94,7 +122,7 @@ __global__ __launch_bounds__(256) void k_fused_ks_mac(DevCtx c, const u64 *__res
     const Mod m = c.mods[ki];
     U128 a00{0, 0}, a01{0, 0}, a10{0, 0}, a11{0, 0};
     for (int J = 0; J < nl; J++) {
-      const u64 *xs = (J == I) ? c2ntt + (ct * nl + J) * N + k : dec + ((ct * (nl + 1) + I) * nl + J) * N + k;
+      const u64 *xs = (ntt && J == I) ? ntt + ct * ntt_stride + (size_t)J * N + k : dec + ((ct * (nl + 1) + I) * nl + J) * N + k;
       const u64x2 x = *reinterpret_cast<const u64x2 *>(xs);
       const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)J * 2 + 0) * c.K + ki) * N + k);
       const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)J * 2 + 1) * c.K + ki) * N + k);
@@ -132,13 +160,16 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_special_intt(DevCtx
       0, 0);
 }
 
+// K3, CKKS: out[ct][comp][j] = (ksacc - NTT_j(tlast mod q_j + fix)) * q_sp^-1 (+ addend)
 template <int LB, bool GUARD>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown(DevCtx c, const u64 *__restrict__ ksacc,
-                                                                     const u64 *__restrict__ tlast, const u64 *__restrict__ c01,
-                                                                     u64 *__restrict__ out, int nl) {
+                                                                     const u64 *__restrict__ tlast, const u64 *__restrict__ addend,
+                                                                     size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl) {
   __shared__ u64 lds[lds_words(LB)];
   const int j = blockIdx.x % nl;
   const size_t cc = blockIdx.x / nl;  // ct*2 + comp
+  const size_t ct = cc >> 1;
+  const int comp = (int)(cc & 1);
   const size_t N = (size_t)1 << LB;
   const Mod m = c.mods[j];
   const NttTable t = ntt_table(c, j);
@@ -148,73 +179,185 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown(DevCtx c, c
   const u64 inv = c.cst->inv_special[j], inv_s = c.cst->inv_special_s[j];
   const u64 *__restrict__ src = tlast + cc * N;
   const u64 *__restrict__ ks = ksacc + (cc * nl + j) * N;
-  const u64 *__restrict__ cin = c01 + (cc * nl + j) * N;
   u64 *__restrict__ o = out + (cc * nl + j) * N;
-  ntt_fwd_block<LB, GUARD>(
-      lds, [&](int, int i) { return add_mod(reduce64(src[i], m), fix, m.q); },
-      [&](int, int i, u64 v) {
-        const u64 x = canon_fwd<GUARD>(v, m);
-        o[i] = add_mod(mul_shoup(sub_mod(ks[i], x, m.q), inv, inv_s, m.q), cin[i], m.q);
-      },
-      t, m, 0, 0);
+  auto ld = [&](int, int i) { return add_mod(reduce64(src[i], m), fix, m.q); };
+  if (addend && (comp == 0 || add_c1)) {  // workgroup-uniform: two straight-line bodies, no per-element select
+    const u64 *__restrict__ cin = addend + ct * addend_stride + ((size_t)comp * nl + j) * N;
+    ntt_fwd_block<LB, GUARD>(
+        lds, ld,
+        [&](int, int i, u64 v) {
+          const u64 x = canon_fwd<GUARD>(v, m);
+          o[i] = add_mod(mul_shoup(sub_mod(ks[i], x, m.q), inv, inv_s, m.q), cin[i], m.q);
+        },
+        t, m, 0, 0);
+  } else {
+    ntt_fwd_block<LB, GUARD>(
+        lds, ld,
+        [&](int, int i, u64 v) {
+          const u64 x = canon_fwd<GUARD>(v, m);
+          o[i] = mul_shoup(sub_mod(ks[i], x, m.q), inv, inv_s, m.q);
+        },
+        t, m, 0, 0);
+  }
 }
 
-static inline unsigned stream_grid(size_t items, int block) {
-  size_t g = (items + block - 1) / block;
-  const size_t cap = 256 * 8 * 4;
-  return (unsigned)(g < cap ? (g ? g : 1) : cap);
+// K3, BFV: out[ct][comp][j] = (INTT_j(ksacc) - (tlast mod q_j + fix)) * q_sp^-1 (+ addend), coefficient form
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_bfv(DevCtx c, const u64 *__restrict__ ksacc,
+                                                                         const u64 *__restrict__ tlast,
+                                                                         const u64 *__restrict__ addend, size_t addend_stride,
+                                                                         int add_c1, u64 *__restrict__ out, int nl) {
+  __shared__ u64 lds[lds_words(LB)];
+  const int j = blockIdx.x % nl;
+  const size_t cc = blockIdx.x / nl;
+  const size_t ct = cc >> 1;
+  const int comp = (int)(cc & 1);
+  const size_t N = (size_t)1 << LB;
+  const Mod m = c.mods[j];
+  const NttTable t = ntt_table(c, j);
+  const u64 half = c.mods[c.K - 1].q >> 1;
+  const u64 hm = reduce64(half, m);
+  const u64 fix = hm ? m.q - hm : 0;
+  const u64 inv = c.cst->inv_special[j], inv_s = c.cst->inv_special_s[j];
+  const u64 *__restrict__ src = tlast + cc * N;
+  const u64 *__restrict__ ks = ksacc + (cc * nl + j) * N;
+  u64 *__restrict__ o = out + (cc * nl + j) * N;
+  auto ld = [&](int, int i) { return ks[i]; };
+  if (addend && (comp == 0 || add_c1)) {
+    const u64 *__restrict__ cin = addend + ct * addend_stride + ((size_t)comp * nl + j) * N;
+    ntt_inv_block<LB>(
+        lds, ld,
+        [&](int, int i, u64 v) {
+          const u64 x = add_mod(reduce64(src[i], m), fix, m.q);
+          o[i] = add_mod(mul_shoup(sub_mod(scale_inv_n(v, m), x, m.q), inv, inv_s, m.q), cin[i], m.q);
+        },
+        t, m, 0, 0);
+  } else {
+    ntt_inv_block<LB>(
+        lds, ld,
+        [&](int, int i, u64 v) {
+          const u64 x = add_mod(reduce64(src[i], m), fix, m.q);
+          o[i] = mul_shoup(sub_mod(scale_inv_n(v, m), x, m.q), inv, inv_s, m.q);
+        },
+        t, m, 0, 0);
+  }
 }
 
-// scratch limbs per ciphertext: c2coef L, c2ntt L, dec L(L+1), ksacc 2L, tsp 2, tlast 2, c01 2L
+// scratch limbs per ciphertext: coef L, ntt L, dec L(L+1), ksacc 2L, tsp 2, tlast 2, c01 2L
 static inline size_t fused_scratch_limbs(int nl) { return (size_t)nl * (nl + 1) + 6 * (size_t)nl + 4; }
 
-template <int LB>
-static int run_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count, size_t chunk, int lanes) {
-  const size_t N = (size_t)1 << LB;
-  const size_t per_ct = fused_scratch_limbs(nl) * N;
-  if (ensure_workspace(c, (size_t)lanes * chunk * per_ct * 8)) return 1;
-  const dim3 block((1 << LB) / 16);
-  bool guard = false;  // unguarded butterflies need (2 logN + 4) q < 2^64 for every key-level prime
+struct FusedScratch {
+  u64 *coef, *ntt, *dec, *ksacc, *tsp, *tlast, *c01;
+};
+static inline FusedScratch carve(u64 *base, size_t chunk, int nl, size_t N) {
+  FusedScratch s;
+  s.coef = base;
+  s.ntt = s.coef + chunk * nl * N;
+  s.dec = s.ntt + chunk * nl * N;
+  s.ksacc = s.dec + chunk * nl * (nl + 1) * N;
+  s.tsp = s.ksacc + chunk * 2 * nl * N;
+  s.tlast = s.tsp + chunk * 2 * N;
+  s.c01 = s.tlast + chunk * 2 * N;
+  return s;
+}
+
+static inline bool needs_guard(const abc_hip_ctx *c) {  // unguarded butterflies need (2 logN + 4) q < 2^64 for every key prime
+  bool guard = false;
   for (int j = 0; j < c->K; j++) guard = guard || !unguarded_ok(c->h_mods[j].bits);
-  if (lanes > 1) {  // fork: the lanes start after everything already queued on the caller's stream
-    ABC_HIP_CHECK(hipEventRecord(c->lane_fork, c->stream));
-    for (int l = 0; l < lanes; l++) ABC_HIP_CHECK(hipStreamWaitEvent(c->lane[l], c->lane_fork, 0));
+  return guard;
+}
+
+// K2a..K3 on one chunk: operand given by (coef, coef_stride) [+ (ntt, ntt_stride) for CKKS], addends by (addend, stride)
+template <int LB>
+static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s, const u64 *coef, size_t coef_stride, const u64 *ntt,
+                           size_t ntt_stride, const u64 *key, const u64 *addend, size_t addend_stride, bool add_c1, u64 *out, int nl,
+                           size_t cc) {
+  const size_t N = (size_t)1 << LB;
+  const dim3 block((1 << LB) / 16);
+  const bool ckks = (c->scheme == 2);
+  const bool guard = needs_guard(c);
+  const unsigned g2a = (unsigned)(cc * (nl + 1) * nl);
+  if (guard)
+    hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, true>), dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
+  else
+    hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, false>), dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
+  hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
+                     ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
+  hipLaunchKernelGGL(k_fused_ks_special_intt<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, s.tsp, s.tlast);
+  const unsigned g3 = (unsigned)(cc * 2 * nl);
+  if (!ckks)
+    hipLaunchKernelGGL(k_fused_ks_moddown_bfv<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
+                       add_c1 ? 1 : 0, out, nl);
+  else if (guard)
+    hipLaunchKernelGGL((k_fused_ks_moddown<LB, true>), dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
+                       add_c1 ? 1 : 0, out, nl);
+  else
+    hipLaunchKernelGGL((k_fused_ks_moddown<LB, false>), dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
+                       add_c1 ? 1 : 0, out, nl);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+struct ChunkPlan {
+  size_t chunk;
+  int lanes;
+};
+// Chunks alternate between two internal streams so that the HBM-streaming kernels of one chunk overlap the ALU-bound
+// transforms of the other; measured on MI355X: 256-pair chunks on two lanes beat one 512-pair chunk per lane.
+static ChunkPlan plan_chunks(const abc_hip_ctx *c, int nl, size_t count) {
+  ChunkPlan p{0, 2};
+  if (const char *e = std::getenv("ABC_HIP_CHUNK")) p.chunk = (size_t)std::atol(e);
+  if (const char *e = std::getenv("ABC_HIP_LANES")) p.lanes = std::atoi(e) >= 2 ? 2 : 1;
+  if (count <= 8) p.lanes = 1;
+  if (!p.chunk) {
+    const size_t per_ct_bytes = fused_scratch_limbs(nl) * c->n * 8;
+    const size_t cap = ((size_t)4 << 30) / per_ct_bytes / (size_t)p.lanes;  // scratch capped at 4 GiB
+    p.chunk = (count + p.lanes - 1) / p.lanes;
+    if (p.chunk > 256) p.chunk = 256;
+    if (p.chunk > cap) p.chunk = cap;
+    if (p.chunk < 1) p.chunk = 1;
   }
-  int turn = 0;
-  for (size_t off = 0; off < count; off += chunk, turn++) {
-    const size_t cc = (count - off < chunk) ? count - off : chunk;
-    const int l = (lanes > 1) ? turn % lanes : 0;
-    hipStream_t st = (lanes > 1) ? c->lane[l] : c->stream;
-    u64 *base = (u64 *)c->ws + (size_t)l * chunk * per_ct;
-    u64 *c2coef = base, *c2ntt = c2coef + chunk * nl * N;
-    u64 *dec = c2ntt + chunk * nl * N;
-    u64 *ksacc = dec + chunk * nl * (nl + 1) * N, *tsp = ksacc + chunk * 2 * nl * N;
-    u64 *tlast = tsp + chunk * 2 * N, *c01 = tlast + chunk * 2 * N;
-    const size_t ctw = 2 * (size_t)nl * N;
-    hipLaunchKernelGGL(k_fused_tensor_intt<LB>, dim3((unsigned)(cc * nl)), block, 0, st, c->dc, a + off * ctw, b + off * ctw, c01,
-                       c2coef, c2ntt, nl);
-    if (guard)
-      hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, true>), dim3((unsigned)(cc * (nl + 1) * nl)), block, 0, st, c->dc, c2coef, dec, nl);
-    else
-      hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, false>), dim3((unsigned)(cc * (nl + 1) * nl)), block, 0, st, c->dc, c2coef, dec, nl);
-    hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, dec, c2ntt,
-                       c->d_relin, ksacc, tsp, nl, cc);
-    hipLaunchKernelGGL(k_fused_ks_special_intt<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, tsp, tlast);
-    if (guard)
-      hipLaunchKernelGGL((k_fused_ks_moddown<LB, true>), dim3((unsigned)(cc * 2 * nl)), block, 0, st, c->dc, ksacc, tlast, c01,
-                         out + off * ctw, nl);
-    else
-      hipLaunchKernelGGL((k_fused_ks_moddown<LB, false>), dim3((unsigned)(cc * 2 * nl)), block, 0, st, c->dc, ksacc, tlast, c01,
-                         out + off * ctw, nl);
-    ABC_HIP_CHECK(hipGetLastError());
-  }
-  if (lanes > 1) {  // join
-    for (int l = 0; l < lanes; l++) {
-      ABC_HIP_CHECK(hipEventRecord(c->lane_join[l], c->lane[l]));
-      ABC_HIP_CHECK(hipStreamWaitEvent(c->stream, c->lane_join[l], 0));
-    }
+  if (p.chunk > count) p.chunk = count;
+  return p;
+}
+
+static int fork_lanes(abc_hip_ctx *c, int lanes) {
+  if (lanes < 2) return 0;
+  ABC_HIP_CHECK(hipEventRecord(c->lane_fork, c->stream));
+  for (int l = 0; l < lanes; l++) ABC_HIP_CHECK(hipStreamWaitEvent(c->lane[l], c->lane_fork, 0));
+  return 0;
+}
+static int join_lanes(abc_hip_ctx *c, int lanes) {
+  if (lanes < 2) return 0;
+  for (int l = 0; l < lanes; l++) {
+    ABC_HIP_CHECK(hipEventRecord(c->lane_join[l], c->lane[l]));
+    ABC_HIP_CHECK(hipStreamWaitEvent(c->stream, c->lane_join[l], 0));
   }
   return 0;
+}
+
+// ---- CKKS multiply + relinearise ----
+template <int LB>
+static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count) {
+  const size_t N = (size_t)1 << LB;
+  const ChunkPlan p = plan_chunks(c, nl, count);
+  const size_t per_ct = fused_scratch_limbs(nl) * N;
+  if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
+  if (fork_lanes(c, p.lanes)) return 1;
+  const size_t ctw = 2 * (size_t)nl * N;
+  int turn = 0;
+  for (size_t off = 0; off < count; off += p.chunk, turn++) {
+    const size_t cc = (count - off < p.chunk) ? count - off : p.chunk;
+    const int l = (p.lanes > 1) ? turn % p.lanes : 0;
+    hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
+    const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, N);
+    hipLaunchKernelGGL(k_fused_tensor_intt<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
+                       b + off * ctw, s.c01, s.coef, s.ntt, nl);
+    if (keyswitch_stage<LB>(c, st, s, s.coef, (size_t)nl * N, s.ntt, (size_t)nl * N, c->d_relin, s.c01, ctw, true, out + off * ctw,
+                            nl, cc))
+      return 1;
+  }
+  return join_lanes(c, p.lanes);
 }
 
 // -1: not applicable (ring too large for an LDS-resident limb) -> caller takes the generic path
@@ -223,30 +366,61 @@ int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
   if (const char *e = std::getenv("ABC_HIP_NO_FUSED"))
     if (e[0] == '1') return -1;
   if (!count) return 0;
-  // chunk: scratch is L(L+1)+6L+4 limbs per ciphertext.  Large grids matter more than cache residency here
-  // (one 1024-thread workgroup per CU, so a launch needs >> 256 workgroups): take the whole batch,
-  // capped at 4 GiB of scratch.
-  size_t chunk = 0;
-  int lanes = 2;
-  if (const char *e = std::getenv("ABC_HIP_CHUNK")) chunk = (size_t)std::atol(e);
-  if (const char *e = std::getenv("ABC_HIP_LANES")) lanes = std::atoi(e) >= 2 ? 2 : 1;
-  if (!chunk) {
-    // every chunk should still be several full waves of 256 workgroups; scratch capped at 4 GiB
-    const size_t per_ct_bytes = fused_scratch_limbs(nl) * c->n * 8;
-    const size_t cap = ((size_t)4 << 30) / per_ct_bytes / (size_t)lanes;
-    chunk = (count + lanes - 1) / lanes;
-    if (chunk > 256) chunk = 256;  // measured on MI355X: 256-pair chunks on two lanes beat one 512-pair chunk per lane
-    if (chunk > cap) chunk = cap;
-    if (chunk < 1) chunk = 1;
-  }
-  if (chunk > count) chunk = count;
-  if (count <= 8) lanes = 1;
   switch (c->logn) {
-    case 10: return run_fused<10>(c, a, b, out, nl, count, chunk, lanes);
-    case 11: return run_fused<11>(c, a, b, out, nl, count, chunk, lanes);
-    case 12: return run_fused<12>(c, a, b, out, nl, count, chunk, lanes);
-    case 13: return run_fused<13>(c, a, b, out, nl, count, chunk, lanes);
-    case 14: return run_fused<14>(c, a, b, out, nl, count, chunk, lanes);
+    case 10: return run_mul_relin<10>(c, a, b, out, nl, count);
+    case 11: return run_mul_relin<11>(c, a, b, out, nl, count);
+    case 12: return run_mul_relin<12>(c, a, b, out, nl, count);
+    case 13: return run_mul_relin<13>(c, a, b, out, nl, count);
+    case 14: return run_mul_relin<14>(c, a, b, out, nl, count);
+    default: return -1;
+  }
+}
+
+// ---- general key switch: out[ct] = KeySwitch(target[ct]) (+ addend) ----
+// target: [nl][N] per ciphertext at target + ct*target_stride, in the ciphertext's own form (BFV coefficient, CKKS NTT)
+template <int LB>
+static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count,
+                         const u64 *addend, size_t addend_stride, bool add_c1) {
+  const size_t N = (size_t)1 << LB;
+  const bool ckks = (c->scheme == 2);
+  const ChunkPlan p = plan_chunks(c, nl, count);
+  const size_t per_ct = fused_scratch_limbs(nl) * N;
+  if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
+  if (fork_lanes(c, p.lanes)) return 1;
+  int turn = 0;
+  for (size_t off = 0; off < count; off += p.chunk, turn++) {
+    const size_t cc = (count - off < p.chunk) ? count - off : p.chunk;
+    const int l = (p.lanes > 1) ? turn % p.lanes : 0;
+    hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
+    const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, N);
+    const u64 *tg = target + off * target_stride;
+    const u64 *coef = tg;
+    size_t coef_stride = target_stride;
+    if (ckks) {  // operand arrives in NTT form: coefficient form via one in-LDS inverse transform per limb
+      hipLaunchKernelGGL(k_fused_operand_intt<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride,
+                         s.coef, nl);
+      coef = s.coef;
+      coef_stride = (size_t)nl * N;
+    }
+    if (keyswitch_stage<LB>(c, st, s, coef, coef_stride, tg, target_stride, key, addend ? addend + off * addend_stride : nullptr,
+                            addend_stride, add_c1, out + off * 2 * nl * N, nl, cc))
+      return 1;
+  }
+  return join_lanes(c, p.lanes);
+}
+
+int keyswitch_fused(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count,
+                    const u64 *addend, size_t addend_stride, bool add_c1) {
+  if (c->logn > 14) return -1;
+  if (const char *e = std::getenv("ABC_HIP_NO_FUSED"))
+    if (e[0] == '1') return -1;
+  if (!count) return 0;
+  switch (c->logn) {
+    case 10: return run_keyswitch<10>(c, target, target_stride, key, out, nl, count, addend, addend_stride, add_c1);
+    case 11: return run_keyswitch<11>(c, target, target_stride, key, out, nl, count, addend, addend_stride, add_c1);
+    case 12: return run_keyswitch<12>(c, target, target_stride, key, out, nl, count, addend, addend_stride, add_c1);
+    case 13: return run_keyswitch<13>(c, target, target_stride, key, out, nl, count, addend, addend_stride, add_c1);
+    case 14: return run_keyswitch<14>(c, target, target_stride, key, out, nl, count, addend, addend_stride, add_c1);
     default: return -1;
   }
 }

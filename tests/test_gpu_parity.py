@@ -206,3 +206,24 @@ def test_other_ring_sizes_ntt(oracle_mod, capi, logn):
     f = g.ntt(x, 0, 0)
     _report("ntt 2^%d fwd" % logn, f, np.stack([o.ntt(0, r) for r in x]))
     _report("ntt 2^%d inv" % logn, g.ntt(f, 0, 0, inverse=True), x)
+
+
+# ---------------- both kernel paths: LDS-resident (default, N <= 2^14) and generic ----------------
+def test_generic_kernels_agree_with_fused(bfv, ckks, oracle_mod, monkeypatch):
+    o, g = bfv
+    a, b = _enc(o, oracle_mod, D1, 1), _enc(o, oracle_mod, D2, 2)
+    oc, gc, x, y, cx, cy, scale = ckks
+    monkeypatch.setenv("ABC_HIP_NO_FUSED", "1")
+    m3 = o.multiply(a, b)
+    _report("generic bfv relinearize", g.relinearize(m3), o.relinearize(m3))
+    _report("generic bfv rotate", g.rotate(a, 5), o.rotate(a, 5))
+    _report("generic ckks mul_relin", gc.mul_relin(cx, cy), oc.mul_relin(cx, cy))
+    _report("generic ckks rotate", gc.rotate(cx, -7), oc.rotate(cx, -7))
+    monkeypatch.delenv("ABC_HIP_NO_FUSED")
+    _report("fused bfv relinearize", g.relinearize(m3), o.relinearize(m3))
+    _report("fused bfv rotate", g.rotate(a, 5), o.rotate(a, 5))
+    _report("fused ckks rotate", gc.rotate(cx, -7), oc.rotate(cx, -7))
+    rs = oc.rescale(oc.mul_relin(cx, cy))
+    _report("fused ckks rotate at level 3", gc.rotate(rs, 64), oc.rotate(rs, 64))
+    ks = oc.keyswitch(cx[1], oc.relin_key())
+    _report("fused raw keyswitch", gc.keyswitch(cx[1], 0), ks)
