@@ -93,8 +93,11 @@ __device__ __forceinline__ void inv_pass(u64 (&x)[16], const int (&hi)[16 >> R],
   }
 }
 
-// Index bookkeeping of one pass: thread `tid` of T = 2^LB/16 owns groups p_g = tid + T*g; group p has
-// lo = p mod G, hi = p / G (G = 2^(LB-S-R)); its k-th element sits at (hi << (LB-S)) + (k << logG) + lo.
+// Index bookkeeping of one pass: group p has lo = p mod G, hi = p / G (G = 2^(LB-S-R)); its k-th element sits at
+// (hi << (LB-S)) + (k << logG) + lo.  Group ownership is wave-contiguous: lane l of wave w owns groups
+// w*64*NG + g*64 + l.  For the first pass (NG = 1) that is simply p = tid; for every later pass (S >= LB-10) a
+// wave's 64*NG groups cover exactly the contiguous block of 1024 coefficients [1024 w, 1024 (w+1)), so those
+// passes only touch LDS words written by the same wave and need no workgroup barrier (see wave_sync).
 template <int LB, int S, int R>
 struct PassIdx {
   static constexpr int T = (1 << LB) / 16;
@@ -105,7 +108,7 @@ struct PassIdx {
   __device__ __forceinline__ static void groups(int tid, int (&hi)[NG], int (&lo)[NG]) {
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-      int p = tid + T * g;
+      int p = (tid >> 6) * (64 * NG) + g * 64 + (tid & 63);
       hi[g] = p >> LOGG;
       lo[g] = p & (G - 1);
     }
@@ -128,6 +131,14 @@ __device__ __forceinline__ void lds_store(u64 *lds, const u64 (&x)[16], const in
   for (int g = 0; g < P::NG; g++)
 #pragma unroll
     for (int k = 0; k < (1 << R); k++) lds[lds_pad(P::elem(hi[g], lo[g], k))] = x[g * (1 << R) + k];
+}
+
+// Exchange through LDS between two passes that are local to a wave: DS operations of one wave execute in
+// issue order, so only the compiler must be kept from reordering them across this point.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Pass schedules (sum = LB, last forward pass has R = 2 so each lane ends with 32-byte contiguous runs).
@@ -187,7 +198,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
       lds_store<LB, S, R>(lds, x, hi, lo);  // in place: a thread rewrites exactly the words it read
     }
   }
-  __syncthreads();
+  wave_sync();  // passes after the first are local to a wave (PassIdx): no workgroup barrier
   {  // pass 2
     constexpr int S = SC::R0 + SC::R1, R = SC::R2;
     using P = PassIdx<LB, S, R>;
@@ -207,7 +218,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     }
   }
   if constexpr (SC::R3 != 0) {
-    __syncthreads();
+    wave_sync();
     constexpr int S = SC::R0 + SC::R1 + SC::R2, R = SC::R3;
     using P = PassIdx<LB, S, R>;
     int hi[P::NG], lo[P::NG];
@@ -246,7 +257,7 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
       for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
     inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
-    __syncthreads();
+    wave_sync();  // all passes but the last are local to a wave
   }
   {
     constexpr int S = SB, R = SC::R2;
@@ -263,7 +274,7 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
     }
     inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
-    __syncthreads();
+    wave_sync();
   }
   {
     constexpr int S = SA, R = SC::R1;
@@ -298,10 +309,10 @@ __device__ __forceinline__ int first_fwd_elem(int r) {
   const int p = threadIdx.x + P::T * (r >> R);
   return P::elem(p >> P::LOGG, p & (P::G - 1), r & ((1 << R) - 1));
 }
-// element held by register slot r in the last forward pass (= first inverse pass): 4*(tid + T*g) + k
+// element held by register slot r = 4g+k in the last forward pass (= first inverse pass): 4*(256 w + 64 g + lane) + k
 template <int LB>
 __device__ __forceinline__ int last_fwd_elem(int r) {
-  return ((threadIdx.x + ((1 << LB) / 16) * (r >> 2)) << 2) + (r & 3);
+  return ((((int)threadIdx.x >> 6) * 256 + (r >> 2) * 64 + ((int)threadIdx.x & 63)) << 2) + (r & 3);
 }
 
 // lazily reduced [0,4q) -> [0,q)
