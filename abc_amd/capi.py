@@ -30,6 +30,7 @@ SYMBOLS = [
     "abc_hip_rotate", "abc_hip_apply_galois", "abc_hip_multiply_plain", "abc_hip_add_plain", "abc_hip_sub_plain",
     "abc_hip_rescale", "abc_hip_mod_switch", "abc_hip_ntt_forward", "abc_hip_ntt_inverse", "abc_hip_keyswitch",
     "abc_hip_microbench", "abc_hip_timer_start", "abc_hip_timer_stop",
+    "abc_hip_ntt_limbs",
     "abc_hip_graph_begin", "abc_hip_graph_end", "abc_hip_graph_launch", "abc_hip_graph_destroy",
 ]
 
@@ -308,6 +309,16 @@ class Context:
         buf = self.upload(d2)
         self.op("ntt_inverse" if inverse else "ntt_forward", buf.ptr, kind, index, C.c_size_t(d2.shape[0]))
         r = self.download(buf, d2.shape).reshape(d.shape)
+        buf.free()
+        return r
+
+    def ntt_limbs(self, data, inverse=False):
+        """[polys][nl][N] coefficient form <-> NTT form at a data level (limb j modulo q_j)."""
+        d = np.ascontiguousarray(data, dtype=np.uint64)
+        d3 = d.reshape(-1, d.shape[-2], self.n)
+        buf = self.upload(d3)
+        self.op("ntt_limbs", buf.ptr, d3.shape[1], C.c_size_t(d3.shape[0]), 1 if inverse else 0)
+        r = self.download(buf, d3.shape).reshape(d.shape)
         buf.free()
         return r
 

@@ -703,6 +703,13 @@ static int ntt_entry(abc_hip_ctx *c, uint64_t *d, int kind, int index, size_t co
 int abc_hip_ntt_forward(abc_hip_ctx *c, uint64_t *d, int kind, int index, size_t count) { CTX_GUARD(c); return ntt_entry(c, d, kind, index, count, true); }
 int abc_hip_ntt_inverse(abc_hip_ctx *c, uint64_t *d, int kind, int index, size_t count) { CTX_GUARD(c); return ntt_entry(c, d, kind, index, count, false); }
 
+int abc_hip_ntt_limbs(abc_hip_ctx *c, uint64_t *d, int nl, size_t polys, int inverse) {
+  CTX_GUARD(c);
+  if (nl < 1 || nl > c->L) { set_error("ntt_limbs: limb count out of range"); return 1; }
+  const LimbMap map = key_limb_map(c, nl);
+  return inverse ? launch_ntt_inv(c, d, map, nl, polys * nl) : launch_ntt_fwd(c, d, map, nl, polys * nl);
+}
+
 int abc_hip_keyswitch(abc_hip_ctx *c, const uint64_t *target, uint32_t key_kind, uint64_t *out2, int nl, size_t count) {
   CTX_GUARD(c);
   if (check_level(c, nl)) return 1;

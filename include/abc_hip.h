@@ -132,6 +132,9 @@ int abc_hip_graph_destroy(abc_hip_ctx *ctx, void *graph_exec);
 /* mod_kind: 0 = key-level prime `index`, 1 = BEHZ Bsk prime `index`, 2 = plaintext modulus */
 int abc_hip_ntt_forward(abc_hip_ctx *ctx, uint64_t *d_data, int mod_kind, int index, size_t count);
 int abc_hip_ntt_inverse(abc_hip_ctx *ctx, uint64_t *d_data, int mod_kind, int index, size_t count);
+/* forward / inverse transform of whole polynomials at a data level: d_data [polys][nl][N], limb j modulo q_j
+ * (CKKS plaintexts and ciphertexts travel in NTT form; host-side encoders produce coefficient form) */
+int abc_hip_ntt_limbs(abc_hip_ctx *ctx, uint64_t *d_data, int nl, size_t polys, int inverse);
 /* key-switch contribution only: d_target [count][nl][N] -> d_out2 [count][2][nl][N]; key_kind 0 relin, else Galois elt */
 int abc_hip_keyswitch(abc_hip_ctx *ctx, const uint64_t *d_target, uint32_t key_kind, uint64_t *d_out2, int nl, size_t count);
 /* micro-benchmarks of the integer / fp64 pipes (returns elapsed ms for `iters` dependent modmuls per lane) */

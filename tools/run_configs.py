@@ -1,0 +1,206 @@
+"""BASELINE.json configs 2-5 end to end on the product path only (device keygen, encode, encrypt, evaluate, decrypt,
+decode; verification against the cleartext computation in numpy).  Independent circuits are sharded over ranks when
+launched under torch.distributed (`torchrun --nproc-per-node N tools/run_configs.py --config 4`), results gathered on
+rank 0.  These are parity / plumbing cases, not the bench line (bench.py is).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from abc_amd import capi, ckks_encoder
+from abc_amd.sharding import shard_range
+
+
+class Ckks:
+    """Thin helper: batched CKKS ciphertext handles on one device."""
+
+    def __init__(self, n, bits, device, seed=0xABC00001):
+        self.n, self.primes = n, capi.create_primes(n, bits)
+        self.g = capi.Context(capi.CKKS, n, self.primes, device=device)
+        self.g.keygen(seed)
+        self.L = self.g.L
+
+    def encrypt(self, vectors, scale, seed):
+        pl = np.stack([ckks_encoder.encode(v, scale, self.n, self.primes[: self.L]) for v in vectors])
+        buf = self.g.upload(pl)
+        self.g.op("ntt_limbs", buf.ptr, self.L, C.c_size_t(len(vectors)), 0)
+        ct = self.g.alloc(len(vectors) * 2 * self.L * self.n * 8)
+        self.g.op("encrypt", buf.ptr, C.c_uint64(seed), ct.ptr, C.c_size_t(len(vectors)))
+        return ct
+
+    def decrypt(self, ct, count, nl, scale):
+        pl = self.g.alloc(count * nl * self.n * 8)
+        self.g.op("decrypt", ct.ptr, 2, nl, pl.ptr, C.c_size_t(count))
+        self.g.op("ntt_limbs", pl.ptr, nl, C.c_size_t(count), 1)
+        res = self.g.download(pl, (count, nl, self.n))
+        return [ckks_encoder.decode(r, scale, self.n, self.primes) for r in res]
+
+
+def config2(dev, rank, world, batch):
+    """BFV N=2^12, 2 limbs: ct x ct multiply + relinearize."""
+    n = 4096
+    g = capi.Context.bfv_default(n, device=dev)
+    g.keygen(0xABC00001)
+    a0, a1 = shard_range(batch, rank, world)
+    cnt = a1 - a0
+    rng = np.random.default_rng(2)
+    x = rng.integers(0, 1025, size=(batch, n))[a0:a1]  # the reference's value range, ref:test/end-to-end/BoxBlurTest.cpp:123
+    y = rng.integers(0, 1025, size=(batch, n))[a0:a1]
+    cb = C.c_size_t(cnt)
+
+    def enc(v, seed):
+        vb, pl, ct = g.upload(v.astype(np.int64)), g.alloc(cnt * n * 8), g.alloc(cnt * 2 * g.L * n * 8)
+        g.op("batch_encode", vb.ptr, pl.ptr, cb)
+        g.op("encrypt", pl.ptr, C.c_uint64(seed), ct.ptr, cb)
+        return ct
+
+    cx, cy = enc(x, 100 + a0), enc(y, 5000 + a0)
+    out = g.alloc(cnt * 2 * g.L * n * 8)
+    g.op("mul_relin", cx.ptr, cy.ptr, out.ptr, g.L, cb); g.sync()
+    t0 = time.perf_counter()
+    g.op("mul_relin", cx.ptr, cy.ptr, out.ptr, g.L, cb); g.sync()
+    dt = time.perf_counter() - t0
+    pl, vals = g.alloc(cnt * n * 8), g.alloc(cnt * n * 8)
+    g.op("decrypt", out.ptr, 2, g.L, pl.ptr, cb)
+    g.op("batch_decode", pl.ptr, vals.ptr, cb)
+    got = g.download(vals, (cnt, n), np.int64)
+    t = g.t
+    want = (x * y) % t
+    want = np.where(want > t // 2, want - t, want)
+    return bool(np.array_equal(got, want)), cnt, dt
+
+
+def config3(dev, rank, world, batch):
+    """CKKS N=2^14, 4 limbs: dot product (mul+relin, rescale, 13 x rotate+add)."""
+    n, scale = 16384, 2.0 ** 40
+    k = Ckks(n, [50, 40, 40, 40, 50], dev)
+    a0, a1 = shard_range(batch, rank, world)
+    cnt = a1 - a0
+    rng = np.random.default_rng(3)
+    xs, ys = rng.uniform(-1, 1, (batch, n // 2))[a0:a1], rng.uniform(-1, 1, (batch, n // 2))[a0:a1]
+    cx, cy = k.encrypt(xs, scale, 100 + a0), k.encrypt(ys, scale, 9000 + a0)
+    g, cb = k.g, C.c_size_t(cnt)
+    m, r, t = g.alloc(cnt * 2 * 4 * n * 8), g.alloc(cnt * 2 * 3 * n * 8), g.alloc(cnt * 2 * 3 * n * 8)
+
+    def circuit():
+        g.op("mul_relin", cx.ptr, cy.ptr, m.ptr, 4, cb)
+        g.op("rescale", m.ptr, r.ptr, 2, 4, cb)
+        step = n // 4
+        while step >= 1:
+            g.op("rotate", r.ptr, t.ptr, 3, step, cb)
+            g.op("add", r.ptr, t.ptr, r.ptr, 2, 3, cb)
+            step //= 2
+
+    circuit(); g.sync()
+    t0 = time.perf_counter(); circuit(); g.sync(); dt = time.perf_counter() - t0
+    dec = k.decrypt(r, cnt, 3, scale * scale / k.primes[3])
+    err = max(abs(d[0].real - float(np.dot(x, y))) for d, x, y in zip(dec, xs, ys))
+    return bool(err < 1e-3), cnt, dt
+
+
+def config4(dev, rank, world, batch):
+    """CKKS N=2^15: 8x8 box sum on 64x64 images (rotations 1,2,4,64,128,256 + adds)."""
+    n, scale = 32768, 2.0 ** 30
+    k = Ckks(n, [50, 40, 40, 50], dev)
+    a0, a1 = shard_range(batch, rank, world)
+    cnt = a1 - a0
+    rng = np.random.default_rng(4)
+    imgs = rng.integers(0, 1025, size=(batch, 64, 64)).astype(np.float64)[a0:a1]
+    ct = k.encrypt(imgs.reshape(cnt, -1), scale, 100 + a0)
+    g, cb = k.g, C.c_size_t(cnt)
+    acc, t = g.alloc(cnt * 2 * 3 * n * 8), g.alloc(cnt * 2 * 3 * n * 8)
+
+    def circuit():
+        g.op("memcpy_d2d", acc.ptr, ct.ptr, C.c_size_t(cnt * 2 * 3 * n * 8))
+        for r in (1, 2, 4, 64, 128, 256):
+            g.op("rotate", acc.ptr, t.ptr, 3, r, cb)
+            g.op("add", acc.ptr, t.ptr, acc.ptr, 2, 3, cb)
+
+    circuit(); g.sync()
+    t0 = time.perf_counter(); circuit(); g.sync(); dt = time.perf_counter() - t0
+    dec = k.decrypt(acc, cnt, 3, scale)
+    ok = True
+    for d, im in zip(dec, imgs):
+        ref = sum(np.roll(np.roll(im, -dx, axis=0), -dy, axis=1) for dx in range(8) for dy in range(8))
+        ok = ok and np.abs(d.real[:4096].reshape(64, 64)[:56, :56] - ref[:56, :56]).max() < 1e-2
+    return bool(ok), cnt, dt
+
+
+def config5(dev, rank, world, batch):
+    """BFV N=2^16: depth-8 multiply chain."""
+    n = 65536
+    primes = capi.create_primes(n, [55] * 8 + [56])
+    t = capi.plain_modulus_batching(n, 20)
+    g = capi.Context(capi.BFV, n, primes, t, device=dev)
+    g.keygen(0xABC00001)
+    a0, a1 = shard_range(batch, rank, world)
+    cnt = a1 - a0
+    cb = C.c_size_t(cnt)
+    rng = np.random.default_rng(5)
+    vals = rng.integers(1, 8, size=(9, batch, n))[:, a0:a1]
+    cts = []
+    for j in range(9):
+        vb, pl, ct = g.upload(vals[j].astype(np.int64)), g.alloc(cnt * n * 8), g.alloc(cnt * 2 * g.L * n * 8)
+        g.op("batch_encode", vb.ptr, pl.ptr, cb)
+        g.op("encrypt", pl.ptr, C.c_uint64(1000 * j + a0), ct.ptr, cb)
+        cts.append(ct)
+    acc = g.alloc(cnt * 2 * g.L * n * 8)
+
+    def circuit():
+        g.op("mul_relin", cts[0].ptr, cts[1].ptr, acc.ptr, g.L, cb)
+        for j in range(2, 9):
+            g.op("mul_relin", acc.ptr, cts[j].ptr, acc.ptr, g.L, cb)
+
+    circuit(); g.sync()
+    t0 = time.perf_counter(); circuit(); g.sync(); dt = time.perf_counter() - t0
+    pl, out = g.alloc(cnt * n * 8), g.alloc(cnt * n * 8)
+    g.op("decrypt", acc.ptr, 2, g.L, pl.ptr, cb)
+    g.op("batch_decode", pl.ptr, out.ptr, cb)
+    got = g.download(out, (cnt, n), np.int64) % t
+    want = np.ones((cnt, n), dtype=np.int64)
+    for j in range(9):
+        want = (want * vals[j]) % t
+    return bool(np.array_equal(got, want)), cnt, dt
+
+
+CONFIGS = {2: (config2, 256), 3: (config3, 32), 4: (config4, 32), 5: (config5, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, nargs="*", default=[2, 3, 4, 5])
+    ap.add_argument("--batch", type=int, default=0, help="independent circuits in total (default: per-config)")
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    for cfg in args.config:
+        fn, default_batch = CONFIGS[cfg]
+        batch = args.batch or default_batch * world
+        ok, cnt, dt = fn(dev, rank, world, batch)
+        line = {"config": cfg, "rank": rank, "circuits": cnt, "verified": ok, "seconds": dt, "circuits_per_s": cnt / dt}
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            tt = torch.tensor([float(ok), dt], dtype=torch.float64, device="cuda")
+            mn = tt.clone(); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            line.update({"all_verified": bool(mn[0] > 0.5), "total_circuits": batch, "total_circuits_per_s": batch / float(mx[1])})
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if not ok:
+            raise SystemExit("config %d: verification failed on rank %d" % (cfg, rank))
+
+
+if __name__ == "__main__":
+    main()
