@@ -2,7 +2,7 @@
 // TypeCheckingVisitor and RuntimeVisitor (compiled from /root/reference by oracle/build_ref.sh) drive this
 // repository's HipCiphertextFactory through ABC's real AbstractCiphertext / AbstractCiphertextFactory headers
 // (abc_amd/runtime compiled with -DABC_HIP_USE_REFERENCE_HEADERS).  Programs and expected slot values are
-// those of test/runtime/RuntimeVisitorTest.cpp (:67-107, :224-262, :264-342, :509-547, :549-594).
+// those of test/runtime/RuntimeVisitorTest.cpp (:67-107, :195-222, :224-262, :264-342, :509-547, :549-594, :596-626).
 // The binary lands in oracle/_ref/ and runs on the GPU box (tests/test_host_runtime.py, -m gpu).
 #include <iostream>
 #include <string>
@@ -72,6 +72,12 @@ int main() {
   runCase(factory, "testForLoop", in0,
           "int LIMIT = 10; secret int result = 0; for (int i = 0; i < LIMIT; i = i + 1) { result = result + __input0__; } return;",
           "y = result;", {"__input0__"}, {{"y", {430, 10, 10, 10, 220, 110, 4250, 0, 10, 70}}});
+  runCase(factory, "testFullAssignmentToCiphertext", "",
+          "secret int fixedKey = {3, 2, 1, 3, 4, 9, 11, 333, 22, 434, 3430, 2211}; return;", "result = fixedKey;", {},
+          {{"result", {3, 2, 1, 3, 4, 9, 11, 333, 22, 434, 3430, 2211}}});
+  runCase(factory, "secret declaration inside the program", "",
+          "secret int sum = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10}; return sum;", "y = sum;", {},
+          {{"y", {1, 2, 3, 4, 5, 6, 7, 8, 9, 10}}});
   std::cout << (failures ? "FAILED " : "passed ") << "reference RuntimeVisitor over HipCiphertextFactory, failures=" << failures
             << std::endl;
   return failures ? 1 : 0;

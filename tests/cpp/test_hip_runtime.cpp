@@ -137,6 +137,12 @@ int main() {
     expectPrefix(outputOf(f, out, "c"), {5, 4, 3});
     expectPrefix(outputOf(f, out, "d"), {4, 4, 4});
   });
+  t.run("testFullAssignmentToCiphertext", [&] {
+    CircuitRuntime rt(f, "");
+    rt.executeAst("secret int fixedKey = {3, 2, 1, 3, 4, 9, 11, 333, 22, 434, 3430, 2211}; return;");
+    auto out = rt.getOutput("result = fixedKey;");
+    expectPrefix(outputOf(f, out, "result"), {3, 2, 1, 3, 4, 9, 11, 333, 22, 434, 3430, 2211});
+  });
   t.run("must-throw programs", [&] {
     CircuitRuntime rt(f, in0);
     EXPECT_THROWS(rt.executeAst("secret int r = __input0__ / __input0__;"));
