@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libabc_hip.so")
+LIB_PATH = os.environ.get("ABC_HIP_LIB") or os.path.join(_HERE, "libabc_hip.so")  # override: A/B of two builds
 
 BFV, CKKS = 1, 2
 u64p = C.POINTER(C.c_uint64)

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void k_mb_fma64(const Mod *mods, u64 *sink, in
 
 // which: 0 Shoup lazy modmul, 1 Barrett modmul, 2 fp64 modmul, 3 64x64->128 product, 4 fp64 FMA.
 // Each lane performs 4*iters operations; grid = 256 CUs x 8 workgroups x 256 lanes.
+int microbench_instr(abc_hip_ctx *c, int which, int iters, double *ms);
 int microbench(abc_hip_ctx *c, int which, int iters, double *ms) {
+  if (which >= 100) return microbench_instr(c, which - 100, iters, ms);
   const int blocks = 256 * 8, threads = 256;
   if (ensure_workspace(c, (size_t)blocks * threads * 8)) return 1;
   u64 *sink = (u64 *)c->ws;
@@ -102,4 +104,54 @@ int microbench(abc_hip_ctx *c, int which, int iters, double *ms) {
   return 0;
 }
 
+}  // namespace abc
+
+// ---- raw instruction issue-rate probes (inline asm, 8 independent instructions per iteration) ----
+namespace abc {
+#define ABC_ASM8(INS)                                                                                                   \
+  asm volatile(INS "\n" INS "\n" INS "\n" INS "\n" INS "\n" INS "\n" INS "\n" INS "\n" ::: "v10", "v11", "v12", "v13", "vcc")
+
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_mb_instr(u64 *sink, int iters) {
+  u32 a = threadIdx.x | 1, b = blockIdx.x | 3;
+  asm volatile("v_mov_b32 v10, %0\n v_mov_b32 v11, %1\n v_mov_b32 v12, 0\n v_mov_b32 v13, 0\n" ::"v"(a), "v"(b) : "v10", "v11", "v12", "v13");
+  for (int i = 0; i < iters; i++) {
+    if (WHICH == 0) ABC_ASM8("v_mad_u64_u32 v[12:13], vcc, v10, v11, v[12:13]");
+    if (WHICH == 1) ABC_ASM8("v_mul_lo_u32 v12, v10, v11");
+    if (WHICH == 2) ABC_ASM8("v_mul_hi_u32 v12, v10, v11");
+    if (WHICH == 3) ABC_ASM8("v_mul_u32_u24 v12, v10, v11");
+    if (WHICH == 4) ABC_ASM8("v_add_u32 v12, v10, v11");
+    if (WHICH == 5) ABC_ASM8("v_lshl_add_u64 v[12:13], v[10:11], 0, v[12:13]");
+    if (WHICH == 6) ABC_ASM8("v_add_co_u32 v12, vcc, v10, v11");
+    if (WHICH == 7) ABC_ASM8("v_cndmask_b32 v12, v10, v11, vcc");
+    if (WHICH == 8) ABC_ASM8("v_mad_u32_u24 v12, v10, v11, v12");
+    if (WHICH == 9) ABC_ASM8("v_mul_hi_u32_u24 v12, v10, v11");
+  }
+  u32 r;
+  asm volatile("v_mov_b32 %0, v12" : "=v"(r)::"v12");
+  sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+int microbench_instr(abc_hip_ctx *c, int which, int iters, double *ms) {
+  const int blocks = 256 * 4, threads = 256;  // 4 waves per SIMD on every CU
+  if (ensure_workspace(c, (size_t)blocks * threads * 8)) return 1;
+  u64 *sink = (u64 *)c->ws;
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    ABC_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    switch (which) {
+#define ABC_CASE(W) case W: hipLaunchKernelGGL(k_mb_instr<W>, dim3(blocks), dim3(threads), 0, c->stream, sink, iters); break;
+      ABC_CASE(0) ABC_CASE(1) ABC_CASE(2) ABC_CASE(3) ABC_CASE(4) ABC_CASE(5) ABC_CASE(6) ABC_CASE(7) ABC_CASE(8) ABC_CASE(9)
+      default: set_error("microbench: unknown instruction probe"); return 1;
+    }
+    ABC_HIP_CHECK(hipGetLastError());
+    ABC_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    ABC_HIP_CHECK(hipEventSynchronize(c->ev1));
+    float t = 0;
+    ABC_HIP_CHECK(hipEventElapsedTime(&t, c->ev0, c->ev1));
+    if (t < best) best = t;
+  }
+  *ms = best;
+  return 0;
+}
 }  // namespace abc

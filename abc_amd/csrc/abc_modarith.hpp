@@ -111,6 +111,20 @@ __device__ __forceinline__ u64 mul_shoup_lazy(u64 y, u64 w, u64 ws, u64 q) {
   const u32 hi = (u32)(acc >> 32) + y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
   return ((u64)hi << 32) | (u32)acc;
 }
+// Same with a cheaper quotient estimate: the y0*ws0 partial product and the carries out of the two middle
+// partial products are dropped, so the estimate is short by at most 2 and the result lies in [0, 4q).  One
+// v_mad_u64_u32 + two v_mul_hi_u32 instead of one v_mul_hi_u32 + three v_mad_u64_u32 with 64-bit addends.
+__device__ __forceinline__ u64 mul_shoup_lazy4(u64 y, u64 w, u64 ws, u64 q) {
+  const u32 y0 = (u32)y, y1 = (u32)(y >> 32), s0 = (u32)ws, s1 = (u32)(ws >> 32);
+  const u64 h = (u64)y1 * s1 + (u64)__umulhi(y1, s0) + (u64)__umulhi(y0, s1);
+  const u64 nq = 0 - q;
+  const u32 w0 = (u32)w, w1 = (u32)(w >> 32);
+  const u32 h0 = (u32)h, h1 = (u32)(h >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+  u64 acc = (u64)y0 * w0;
+  acc = (u64)h0 * n0 + acc;
+  const u32 hi = (u32)(acc >> 32) + y0 * w1 + y1 * w0 + h0 * n1 + h1 * n0;
+  return ((u64)hi << 32) | (u32)acc;
+}
 __device__ __forceinline__ u64 mul_shoup(u64 y, u64 w, u64 ws, u64 q) {
   u64 r = mul_shoup_lazy(y, w, ws, q);
   return r >= q ? r - q : r;

@@ -34,10 +34,11 @@ struct NttTable {
 
 // ---- one radix-2^R register pass over NG = 16>>R groups -------------------------------------------
 // Forward (CT): stages S..S+R-1 of the block-local transform.
-// GUARD = false: no per-stage correction of X; every stage adds at most 2q to a value, so after all
-// logN stages a canonical input stays below (2 logN + 1) q -- usable whenever that fits 64 bits (q < 2^58
-// for N <= 2^16), which holds for every SEAL default prime up to N = 16384 and for the CKKS chains here; only
-// the 61-bit BEHZ primes (and 59/60-bit user primes) take the guarded form.
+// GUARD = false: no per-stage correction of X and the cheaper quotient estimate (mul_shoup_lazy4, product in
+// [0,4q)); every stage then adds at most 4q to a value, so after all logN <= 14 stages of a block a canonical
+// input stays below (4*14 + 1) q = 57q -- usable whenever that fits 64 bits (q <= 57 bits), which holds for every
+// SEAL default prime up to N = 32768 and for the CKKS chains here; the 61-bit BEHZ primes (and 58..60-bit user
+// primes) take the guarded form.
 template <int LB, int S, int R, bool UNIFORM, bool GUARD = true>
 __device__ __forceinline__ void fwd_pass(u64 (&x)[16], const int (&hi)[16 >> R], const NttTable &t, u64 q, u64 two_q,
                                          int S0, int b) {
@@ -57,10 +58,17 @@ __device__ __forceinline__ void fwd_pass(u64 (&x)[16], const int (&hi)[16 >> R],
         u64 w = t.tw[idx], ws = t.tws[idx];
         u64 &X = x[g * (1 << R) + k];
         u64 &Y = x[g * (1 << R) + (k | half)];
-        u64 a = GUARD ? csub(X, two_q) : X;
-        u64 v = mul_shoup_lazy(Y, w, ws, q);
-        X = a + v;
-        Y = a + two_q - v;
+        if (GUARD) {
+          const u64 a = csub(X, two_q);
+          const u64 v = mul_shoup_lazy(Y, w, ws, q);
+          X = a + v;
+          Y = a + two_q - v;
+        } else {
+          const u64 a = X;
+          const u64 v = mul_shoup_lazy4(Y, w, ws, q);
+          X = a + v;
+          Y = a + (two_q << 1) - v;
+        }
       }
     }
   }
@@ -317,8 +325,9 @@ __device__ __forceinline__ int last_fwd_elem(int r) {
 
 // lazily reduced [0,4q) -> [0,q)
 __device__ __forceinline__ u64 canon4(u64 v, const Mod &m) { return csub(csub(v, m.two_q), m.q); }
-// output of an unguarded forward transform, [0,32q) -> [0,q)
+// output of an unguarded forward transform, [0,64q) -> [0,q)
 __device__ __forceinline__ u64 canon32(u64 v, const Mod &m) {
+  v = csub(v, m.two_q << 4);
   v = csub(v, m.two_q << 3);
   v = csub(v, m.two_q << 2);
   v = csub(v, m.two_q << 1);
@@ -326,8 +335,8 @@ __device__ __forceinline__ u64 canon32(u64 v, const Mod &m) {
 }
 template <bool GUARD>
 __device__ __forceinline__ u64 canon_fwd(u64 v, const Mod &m) { return GUARD ? canon4(v, m) : canon32(v, m); }
-// a modulus may skip the per-stage guard when (2 logN + 4) q < 2^64
-__host__ __device__ __forceinline__ bool unguarded_ok(u32 bits) { return bits <= 58; }
+// a modulus may take the unguarded butterflies when 64 q <= 2^64
+__host__ __device__ __forceinline__ bool unguarded_ok(u32 bits) { return bits <= 57; }
 // scale by N^-1 and canonicalise (input [0,2q) or any 64-bit value)
 __device__ __forceinline__ u64 scale_inv_n(u64 v, const Mod &m) { return mul_shoup(v, m.inv_n, m.inv_n_s, m.q); }
 

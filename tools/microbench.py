@@ -20,6 +20,16 @@ def main():
         ops = lanes * 4.0 * iters
         res[name] = {"ms": ms, "Gop_per_s": ops / ms / 1e6}
         print("%-20s %8.3f ms  %10.1f Gop/s" % (name, ms, ops / ms / 1e6), flush=True)
+    # raw instruction issue rates: 1024 workgroups x 4 waves, 8 instructions per iteration
+    INSTR = {100: "v_mad_u64_u32", 101: "v_mul_lo_u32", 102: "v_mul_hi_u32", 103: "v_mul_u32_u24", 104: "v_add_u32",
+             105: "v_lshl_add_u64", 106: "v_add_co_u32", 107: "v_cndmask_b32", 108: "v_mad_u32_u24", 109: "v_mul_hi_u32_u24"}
+    it = 8192
+    for which, name in INSTR.items():
+        ms = g.microbench(which, it)
+        # wave-instructions per SIMD: 4 waves x it x 8; cycles at 2.4 GHz
+        cyc = ms * 1e-3 * 2.4e9 / (4 * it * 8)
+        res[name] = {"ms": ms, "cycles_per_wave_instr_at_2.4GHz": cyc}
+        print("%-20s %8.3f ms  %6.2f cycles per wave-instruction (if 2.4 GHz)" % (name, ms, cyc), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/microbench.json", "w") as f:
         json.dump(res, f, indent=1)
