@@ -441,14 +441,16 @@ int abc_hip_ctx_create(int scheme, int logn, const uint64_t *primes, int nprimes
   }
   if (!rc) c->stream = c->own_stream;  // operations run on a private stream unless abc_hip_set_stream overrides it
   if (!rc && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-              hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming) != hipSuccess ||
-              hipEventCreateWithFlags(&c->lane_join[0], hipEventDisableTiming) != hipSuccess ||
-              hipEventCreateWithFlags(&c->lane_join[1], hipEventDisableTiming) != hipSuccess ||
-              hipStreamCreateWithFlags(&c->lane[0], hipStreamNonBlocking) != hipSuccess ||
-              hipStreamCreateWithFlags(&c->lane[1], hipStreamNonBlocking) != hipSuccess)) {
-    set_error("hipEventCreate / hipStreamCreate failed");
+              hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming) != hipSuccess)) {
+    set_error("hipEventCreate failed");
     rc = 1;
   }
+  for (int i = 0; !rc && i < abc_hip_ctx::kMaxLanes; i++)
+    if (hipEventCreateWithFlags(&c->lane_join[i], hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->lane[i], hipStreamNonBlocking) != hipSuccess) {
+      set_error("lane stream / event creation failed");
+      rc = 1;
+    }
   if (rc) { abc_hip_ctx_destroy(c); return 1; }
   *out = c;
   return 0;
@@ -467,7 +469,7 @@ void abc_hip_ctx_destroy(abc_hip_ctx *c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->lane_fork) (void)hipEventDestroy(c->lane_fork);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < abc_hip_ctx::kMaxLanes; i++) {
     if (c->lane_join[i]) (void)hipEventDestroy(c->lane_join[i]);
     if (c->lane[i]) (void)hipStreamDestroy(c->lane[i]);
   }

@@ -75,8 +75,9 @@ struct abc_hip_ctx {
   hipStream_t own_stream = nullptr;  // the context's private stream (default)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // two internal lanes let an HBM-streaming kernel of one chunk overlap an ALU-bound transform of another
-  hipStream_t lane[2] = {nullptr, nullptr};
-  hipEvent_t lane_fork = nullptr, lane_join[2] = {nullptr, nullptr};
+  static constexpr int kMaxLanes = 4;
+  hipStream_t lane[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t lane_fork = nullptr, lane_join[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
   // moduli: ids 0..K-1 key primes, then Bsk (B_0..B_{nB-1}, m_sk), gamma, t, m_tilde(arith only)
   std::vector<abc::Mod> h_mods;
   std::vector<uint64_t> mod_values;

@@ -307,7 +307,11 @@ struct ChunkPlan {
 static ChunkPlan plan_chunks(const abc_hip_ctx *c, int nl, size_t count) {
   ChunkPlan p{0, 2};
   if (const char *e = std::getenv("ABC_HIP_CHUNK")) p.chunk = (size_t)std::atol(e);
-  if (const char *e = std::getenv("ABC_HIP_LANES")) p.lanes = std::atoi(e) >= 2 ? 2 : 1;
+  if (const char *e = std::getenv("ABC_HIP_LANES")) {
+    p.lanes = std::atoi(e);
+    if (p.lanes < 1) p.lanes = 1;
+    if (p.lanes > abc_hip_ctx::kMaxLanes) p.lanes = abc_hip_ctx::kMaxLanes;
+  }
   if (count <= 8) p.lanes = 1;
   if (!p.chunk) {
     const size_t per_ct_bytes = fused_scratch_limbs(nl) * c->n * 8;

@@ -143,10 +143,17 @@ __device__ __forceinline__ void lds_store(u64 *lds, const u64 (&x)[16], const in
 
 // Exchange through LDS between two passes that are local to a wave: DS operations of one wave execute in
 // issue order, so only the compiler must be kept from reordering them across this point.
+// Both syncs fence the LDS ("local") address space only, so the compiler may move the global twiddle loads of the
+// next pass above them and their latency hides under the current pass.
 __device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+__device__ __forceinline__ void block_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // Pass schedules (sum = LB, last forward pass has R = 2 so each lane ends with 32-byte contiguous runs).
@@ -188,7 +195,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
   }
-  __syncthreads();
+  block_sync_lds();
   {  // pass 1
     constexpr int S = SC::R0, R = SC::R1;
     using P = PassIdx<LB, S, R>;
@@ -292,7 +299,7 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
     lds_load<LB, S, R>(lds, x, hi, lo);
     inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
-    __syncthreads();
+    block_sync_lds();
   }
   {
     constexpr int S = 0, R = SC::R0;
