@@ -86,7 +86,9 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_intt(DevCtx c,
 // NTT form at ntt + ct*ntt_stride + J*N (used where q_J is the key prime: switch_key_inplace, CKKS branch)
 // ---------------------------------------------------------------------------------------------------------------
 // K2a: dec[ct][I][J] = NTT_I( operand_J mod q_I )
-template <int LB, bool GUARD>
+// LAZY (unguarded transforms over primes <= 55 bits): the transform's raw outputs (< 64q) are stored as they are;
+// the inner product accumulates 128-bit products and reduces once, so it needs no canonical operands.
+template <int LB, bool GUARD, bool LAZY>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_decomp_ntt(DevCtx c, const u64 *__restrict__ coef, size_t coef_stride,
                                                                         u64 *__restrict__ dec, int nl, int skip_diagonal) {
   __shared__ u64 lds[lds_words(LB)];
@@ -103,7 +105,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_decomp_ntt(DevCtx c
   const bool need_reduce = c.mods[J].q > m.q;  // residues are < q_J already
   ntt_fwd_block<LB, GUARD>(
       lds, [&](int, int i) { const u64 v = src[i]; return need_reduce ? reduce64(v, m) : v; },
-      [&](int, int i, u64 v) { dst[i] = canon_fwd<GUARD>(v, m); }, t, m, 0, 0);
+      [&](int, int i, u64 v) { dst[i] = LAZY ? v : canon_fwd<GUARD>(v, m); }, t, m, 0, 0);
 }
 
 // K2b: acc_comp[k] = sum_J x_J[k] * key[J][comp][I][k]; data primes -> ksacc[ct][comp][I], special -> tsp[ct][comp]
@@ -185,17 +187,17 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown(DevCtx c, c
     const u64 *__restrict__ cin = addend + ct * addend_stride + ((size_t)comp * nl + j) * N;
     ntt_fwd_block<LB, GUARD>(
         lds, ld,
-        [&](int, int i, u64 v) {
-          const u64 x = canon_fwd<GUARD>(v, m);
-          o[i] = add_mod(mul_shoup(sub_mod(ks[i], x, m.q), inv, inv_s, m.q), cin[i], m.q);
+        [&](int, int i, u64 v) {  // unguarded: v < 64q, so ks + 64q - v stays positive and mul_shoup reduces it
+          const u64 d = GUARD ? sub_mod(ks[i], canon4(v, m), m.q) : ks[i] + (m.two_q << 5) - v;
+          o[i] = add_mod(mul_shoup(d, inv, inv_s, m.q), cin[i], m.q);
         },
         t, m, 0, 0);
   } else {
     ntt_fwd_block<LB, GUARD>(
         lds, ld,
         [&](int, int i, u64 v) {
-          const u64 x = canon_fwd<GUARD>(v, m);
-          o[i] = mul_shoup(sub_mod(ks[i], x, m.q), inv, inv_s, m.q);
+          const u64 d = GUARD ? sub_mod(ks[i], canon4(v, m), m.q) : ks[i] + (m.two_q << 5) - v;
+          o[i] = mul_shoup(d, inv, inv_s, m.q);
         },
         t, m, 0, 0);
   }
@@ -277,10 +279,17 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
   const bool ckks = (c->scheme == 2);
   const bool guard = needs_guard(c);
   const unsigned g2a = (unsigned)(cc * (nl + 1) * nl);
+  bool lazy = !guard;  // 4 products of a (< 64q) operand with a key residue must stay below 2^(k+63): k <= 55
+  for (int j = 0; j < c->K; j++) lazy = lazy && c->h_mods[j].bits <= 55;
   if (guard)
-    hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, true>), dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
+    hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, true, false>), dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl,
+                       ckks ? 1 : 0);
+  else if (lazy)
+    hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, false, true>), dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl,
+                       ckks ? 1 : 0);
   else
-    hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, false>), dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
+    hipLaunchKernelGGL((k_fused_ks_decomp_ntt<LB, false, false>), dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl,
+                       ckks ? 1 : 0);
   hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
                      ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
   hipLaunchKernelGGL(k_fused_ks_special_intt<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, s.tsp, s.tlast);

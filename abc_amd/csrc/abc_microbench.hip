@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void k_mb_fma64(const Mod *mods, u64 *sink, in
 // which: 0 Shoup lazy modmul, 1 Barrett modmul, 2 fp64 modmul, 3 64x64->128 product, 4 fp64 FMA.
 // Each lane performs 4*iters operations; grid = 256 CUs x 8 workgroups x 256 lanes.
 int microbench_instr(abc_hip_ctx *c, int which, int iters, double *ms);
+int microbench_bfly(abc_hip_ctx *c, int which, int iters, double *ms);
 int microbench(abc_hip_ctx *c, int which, int iters, double *ms) {
+  if (which >= 200) return microbench_bfly(c, which - 200, iters, ms);
   if (which >= 100) return microbench_instr(c, which - 100, iters, ms);
   const int blocks = 256 * 8, threads = 256;
   if (ensure_workspace(c, (size_t)blocks * threads * 8)) return 1;
@@ -144,6 +146,103 @@ int microbench_instr(abc_hip_ctx *c, int which, int iters, double *ms) {
       ABC_CASE(0) ABC_CASE(1) ABC_CASE(2) ABC_CASE(3) ABC_CASE(4) ABC_CASE(5) ABC_CASE(6) ABC_CASE(7) ABC_CASE(8) ABC_CASE(9)
       default: set_error("microbench: unknown instruction probe"); return 1;
     }
+    ABC_HIP_CHECK(hipGetLastError());
+    ABC_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    ABC_HIP_CHECK(hipEventSynchronize(c->ev1));
+    float t = 0;
+    ABC_HIP_CHECK(hipEventElapsedTime(&t, c->ev0, c->ev1));
+    if (t < best) best = t;
+  }
+  *ms = best;
+  return 0;
+}
+}  // namespace abc
+
+// ---- butterfly issue-rate probes: the compiler's unguarded butterfly vs a hand-scheduled instruction sequence ----
+namespace abc {
+__global__ __launch_bounds__(256) void k_mb_bfly_cpp(const Mod *mods, u64 *sink, int iters, u64 w, u64 ws) {
+  const Mod m = mods[0];
+  u64 x[4], y[4];
+  for (int k = 0; k < 4; k++) { x[k] = threadIdx.x + 17 * k + 1; y[k] = blockIdx.x + 31 * k + 5; }
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u64 a = x[k];
+      const u64 v = mul_shoup_lazy4(y[k], w, ws, m.q);
+      x[k] = a + v;
+      y[k] = a + (m.two_q << 1) - v;
+    }
+  }
+  sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = x[0] ^ x[1] ^ x[2] ^ x[3] ^ y[0] ^ y[1] ^ y[2] ^ y[3];
+}
+
+// X in v[0+4k:1+4k], Y in v[2+4k:3+4k]; scratch v[16+8k .. 23+8k]; s[20:21]=ws s[22:23]=w s[24:25]=-q s[26:27]=4q+1
+#define ABC_BFLY_ASM(X0, X1, Y0, Y1, T0, T1, T2, T3, H0, H1, A0, A1, C0, C1)                                             \
+  "v_mul_hi_u32 v" #T0 ", v" #Y1 ", s20\n"                                                                             \
+  "v_mul_hi_u32 v" #T2 ", v" #Y0 ", s21\n"                                                                             \
+  "v_mad_u64_u32 v[" #H0 ":" #H1 "], s[28:29], v" #Y1 ", s21, v[" #T0 ":" #T1 "]\n"                                    \
+  "v_mad_u64_u32 v[" #A0 ":" #A1 "], s[28:29], v" #Y0 ", s22, 0\n"                                                     \
+  "v_mad_u64_u32 v[" #C0 ":" #C1 "], s[28:29], v" #Y0 ", s23, 0\n"                                                     \
+  "v_lshl_add_u64 v[" #H0 ":" #H1 "], v[" #H0 ":" #H1 "], 0, v[" #T2 ":" #T3 "]\n"                                     \
+  "v_mad_u64_u32 v[" #C0 ":" #C1 "], s[28:29], v" #Y1 ", s22, v[" #C0 ":" #C1 "]\n"                                    \
+  "v_mad_u64_u32 v[" #A0 ":" #A1 "], s[28:29], v" #H0 ", s24, v[" #A0 ":" #A1 "]\n"                                    \
+  "v_mad_u64_u32 v[" #C0 ":" #C1 "], s[28:29], v" #H0 ", s25, v[" #C0 ":" #C1 "]\n"                                    \
+  "v_mad_u64_u32 v[" #C0 ":" #C1 "], s[28:29], v" #H1 ", s24, v[" #C0 ":" #C1 "]\n"                                    \
+  "v_lshl_add_u64 v[" #Y0 ":" #Y1 "], v[" #X0 ":" #X1 "], 0, s[26:27]\n"                                               \
+  "v_add_u32 v" #A1 ", v" #A1 ", v" #C0 "\n"                                                                           \
+  "v_lshl_add_u64 v[" #X0 ":" #X1 "], v[" #X0 ":" #X1 "], 0, v[" #A0 ":" #A1 "]\n"                                     \
+  "v_not_b32 v" #A0 ", v" #A0 "\n"                                                                                     \
+  "v_not_b32 v" #A1 ", v" #A1 "\n"                                                                                     \
+  "v_lshl_add_u64 v[" #Y0 ":" #Y1 "], v[" #Y0 ":" #Y1 "], 0, v[" #A0 ":" #A1 "]\n"
+
+__global__ __launch_bounds__(256) void k_mb_bfly_asm(const Mod *mods, u64 *sink, int iters, u64 w, u64 ws) {
+  const Mod m = mods[0];
+  const u64 nq = 0 - m.q, c4 = (m.two_q << 1) + 1;
+  const u32 tid = threadIdx.x, bid = blockIdx.x;
+  asm volatile(
+      "s_mov_b64 s[20:21], %2\n s_mov_b64 s[22:23], %3\n s_mov_b64 s[24:25], %4\n s_mov_b64 s[26:27], %5\n"
+      "v_add_u32 v0, 1, %0\n v_mov_b32 v1, 0\n v_add_u32 v2, 5, %1\n v_mov_b32 v3, 0\n"
+      "v_add_u32 v4, 18, %0\n v_mov_b32 v5, 0\n v_add_u32 v6, 36, %1\n v_mov_b32 v7, 0\n"
+      "v_add_u32 v8, 35, %0\n v_mov_b32 v9, 0\n v_add_u32 v10, 67, %1\n v_mov_b32 v11, 0\n"
+      "v_add_u32 v12, 52, %0\n v_mov_b32 v13, 0\n v_add_u32 v14, 98, %1\n v_mov_b32 v15, 0\n"
+      "v_mov_b32 v17, 0\n v_mov_b32 v19, 0\n v_mov_b32 v25, 0\n v_mov_b32 v27, 0\n"
+      "v_mov_b32 v33, 0\n v_mov_b32 v35, 0\n v_mov_b32 v41, 0\n v_mov_b32 v43, 0\n" ::"v"(tid),
+      "v"(bid), "s"(ws), "s"(w), "s"(nq), "s"(c4)
+      : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
+        "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
+        "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "s20", "s21", "s22", "s23", "s24",
+        "s25", "s26", "s27", "s28", "s29");
+  for (int i = 0; i < iters; i++) {
+    asm volatile(
+        // four butterflies back to back; independent register sets let the hardware overlap their latencies
+        ABC_BFLY_ASM(0, 1, 2, 3, 16, 17, 18, 19, 20, 21, 22, 23, 44, 45)
+        ABC_BFLY_ASM(4, 5, 6, 7, 24, 25, 26, 27, 28, 29, 30, 31, 46, 47)
+        ABC_BFLY_ASM(8, 9, 10, 11, 32, 33, 34, 35, 36, 37, 38, 39, 44, 45)
+        ABC_BFLY_ASM(12, 13, 14, 15, 40, 41, 42, 43, 20, 21, 22, 23, 46, 47)
+        ::
+        : "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
+          "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
+          "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "s28", "s29");
+  }
+  u32 r;
+  asm volatile("v_xor_b32 %0, v0, v2\n v_xor_b32 %0, %0, v4\n v_xor_b32 %0, %0, v6\n v_xor_b32 %0, %0, v8\n v_xor_b32 %0, %0, v10\n"
+               "v_xor_b32 %0, %0, v12\n v_xor_b32 %0, %0, v14\n"
+               : "=&v"(r)::"v0", "v2", "v4", "v6", "v8", "v10", "v12", "v14");
+  sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+int microbench_bfly(abc_hip_ctx *c, int which, int iters, double *ms) {
+  const int blocks = 256 * 4, threads = 256;
+  if (ensure_workspace(c, (size_t)blocks * threads * 8)) return 1;
+  u64 *sink = (u64 *)c->ws;
+  const u64 q = c->h_mods[0].q, w = q / 3 + 12345, ws = (u64)((((unsigned __int128)w) << 64) / q);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    ABC_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    if (which == 0)
+      hipLaunchKernelGGL(k_mb_bfly_cpp, dim3(blocks), dim3(threads), 0, c->stream, c->d_mods, sink, iters, w, ws);
+    else
+      hipLaunchKernelGGL(k_mb_bfly_asm, dim3(blocks), dim3(threads), 0, c->stream, c->d_mods, sink, iters, w, ws);
     ABC_HIP_CHECK(hipGetLastError());
     ABC_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     ABC_HIP_CHECK(hipEventSynchronize(c->ev1));

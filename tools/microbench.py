@@ -30,6 +30,13 @@ def main():
         cyc = ms * 1e-3 * 2.4e9 / (4 * it * 8)
         res[name] = {"ms": ms, "cycles_per_wave_instr_at_2.4GHz": cyc}
         print("%-20s %8.3f ms  %6.2f cycles per wave-instruction (if 2.4 GHz)" % (name, ms, cyc), flush=True)
+    # unguarded butterfly: compiler output vs a hand-scheduled 16-instruction sequence (4 butterflies per iteration)
+    it = 4096
+    for which, name in ((200, "butterfly_cpp"), (201, "butterfly_asm")):
+        ms = g.microbench(which, it)
+        cyc = ms * 1e-3 * 2.4e9 / (4 * it * 4)  # wave-butterflies per SIMD: 4 waves x it x 4
+        res[name] = {"ms": ms, "cycles_per_wave_butterfly_at_2.4GHz": cyc, "Gbutterfly_per_s": 1024 * 256 * 4.0 * it / ms / 1e6}
+        print("%-20s %8.3f ms  %6.1f cycles per wave-butterfly (if 2.4 GHz)  %8.0f Gbfly/s" % (name, ms, cyc, res[name]["Gbutterfly_per_s"]), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/microbench.json", "w") as f:
         json.dump(res, f, indent=1)
