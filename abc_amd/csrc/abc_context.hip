@@ -73,26 +73,25 @@ static Mod make_mod(uint64_t q, int logn, bool ntt) {
   return m;
 }
 
-static void fill_twiddles(uint64_t q, int logn, uint64_t *dst /*[4][N]*/) {
+static void fill_twiddles(uint64_t q, int logn, uint64_t *dst /*[2][N][2]*/) {
   using namespace host;
   const size_t n = (size_t)1 << logn;
   const uint64_t psi = min_primitive_root(2 * n, q);
-  uint64_t *tw = dst, *tws = dst + n, *itw = dst + 2 * n, *itws = dst + 3 * n;
+  uint64_t *fwd = dst, *inv = dst + 2 * n;  // interleaved {w, Shoup quotient}
   uint64_t p = 1;
   for (size_t i = 0; i < n; i++) {
-    tw[bitrev((uint32_t)i, logn)] = p;
+    fwd[2 * (size_t)bitrev((uint32_t)i, logn)] = p;
     p = mulmod(p, psi, q);
   }
-  // inverses: psi^-e = -psi^(N-e); batch through one inversion of psi
   const uint64_t ipsi = invmod(psi, q);
   p = 1;
   for (size_t i = 0; i < n; i++) {
-    itw[bitrev((uint32_t)i, logn)] = p;
+    inv[2 * (size_t)bitrev((uint32_t)i, logn)] = p;
     p = mulmod(p, ipsi, q);
   }
   for (size_t i = 0; i < n; i++) {
-    tws[i] = shoup(tw[i], q);
-    itws[i] = shoup(itw[i], q);
+    fwd[2 * i + 1] = shoup(fwd[2 * i], q);
+    inv[2 * i + 1] = shoup(inv[2 * i], q);
   }
 }
 

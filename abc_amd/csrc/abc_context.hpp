@@ -49,7 +49,7 @@ struct DevConst {
 // passed BY VALUE to every kernel
 struct DevCtx {
   const Mod *mods;      // [nmods]
-  const u64 *tw;        // [nmods][4][N]: tw, tws, itw, itws
+  const u64 *tw;        // [nmods][2][N][2]: forward {w, Shoup} pairs, then inverse pairs
   const DevConst *cst;  //
   const u32 *slot_map;  // [N] BatchEncoder index map (BFV)
   int logn, n;
@@ -60,7 +60,8 @@ struct DevCtx {
 __device__ __forceinline__ NttTable ntt_table(const DevCtx &c, int mid) {
   const u64 *b = c.tw + (size_t)mid * 4 * c.n;
   NttTable t;
-  t.tw = b; t.tws = b + c.n; t.itw = b + 2 * (size_t)c.n; t.itws = b + 3 * (size_t)c.n;
+  t.tw = reinterpret_cast<const u64x2 *>(b);
+  t.itw = reinterpret_cast<const u64x2 *>(b + 2 * (size_t)c.n);
   return t;
 }
 

@@ -102,10 +102,15 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_decomp_ntt(DevCtx c
   const NttTable t = ntt_table(c, ki);
   const u64 *__restrict__ src = coef + ct * coef_stride + (size_t)J * N;
   u64 *__restrict__ dst = dec + ((ct * (nl + 1) + I) * nl + J) * N;
-  const bool need_reduce = c.mods[J].q > m.q;  // residues are < q_J already
-  ntt_fwd_block<LB, GUARD>(
-      lds, [&](int, int i) { const u64 v = src[i]; return need_reduce ? reduce64(v, m) : v; },
-      [&](int, int i, u64 v) { dst[i] = LAZY ? v : canon_fwd<GUARD>(v, m); }, t, m, 0, 0);
+  // residues are < q_J already; the guarded transform accepts inputs < 4q, the unguarded one < 8q (57q of growth
+  // on top stays below the 64q its consumers assume).  Workgroup-uniform choice between two straight-line bodies,
+  // so the sixteen coefficient loads of a lane are issued back to back in either.
+  const bool need_reduce = GUARD ? (c.mods[J].q > m.q) : ((c.mods[J].q >> 3) >= m.q);
+  auto st = [&](int, int i, u64 v) { dst[i] = LAZY ? v : canon_fwd<GUARD>(v, m); };
+  if (need_reduce)
+    ntt_fwd_block<LB, GUARD>(lds, [&](int, int i) { return reduce64(src[i], m); }, st, t, m, 0, 0);
+  else
+    ntt_fwd_block<LB, GUARD>(lds, [&](int, int i) { return src[i]; }, st, t, m, 0, 0);
 }
 
 // K2b: acc_comp[k] = sum_J x_J[k] * key[J][comp][I][k]; data primes -> ksacc[ct][comp][I], special -> tsp[ct][comp]

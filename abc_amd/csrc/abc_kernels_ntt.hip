@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_ntt_fwd_strided(DevCtx c, u64 *data, Li
     for (int k = 0; k < (1 << R); k++) {
       if (k & half) continue;
       const int idx = (1 << u) + (k >> (R - u));
-      const u64 w = t.tw[idx], ws = t.tws[idx];
+      const u64 w = t.tw[idx].x, ws = t.tw[idx].y;
       u64 a = x[k] >= m.two_q ? x[k] - m.two_q : x[k];
       u64 v = mul_shoup_lazy(x[k | half], w, ws, m.q);
       x[k] = a + v;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_ntt_inv_strided(DevCtx c, u64 *data, Li
     for (int k = 0; k < (1 << R); k++) {
       if (k & half) continue;
       const int idx = (1 << u) + (k >> (R - u));
-      const u64 w = t.itw[idx], ws = t.itws[idx];
+      const u64 w = t.itw[idx].x, ws = t.itw[idx].y;
       u64 a = x[k], b2 = x[k | half];
       u64 s = a + b2;
       x[k] = s >= m.two_q ? s - m.two_q : s;

@@ -25,11 +25,11 @@ namespace abc {
 __device__ __forceinline__ int lds_pad(int i) { return i + ((i >> 6) << 2); }
 constexpr int lds_words(int lb) { return (1 << lb) + ((1 << lb) >> 6) * 4; }
 
+// Twiddle tables are interleaved {w, floor(w * 2^64 / q)} pairs so that one 16-byte load (s_load_dwordx4 where the
+// index is wave-uniform, global_load_dwordx4 otherwise) fetches everything a butterfly needs.
 struct NttTable {
-  const u64 *tw;    // [N] forward twiddles, bit-reversed order
-  const u64 *tws;   // [N] Shoup quotients
-  const u64 *itw;   // [N] inverse twiddles (itw[m+i] = tw[m+i]^-1)
-  const u64 *itws;  // [N]
+  const u64x2 *tw;   // [N] forward twiddles {w, Shoup quotient}, bit-reversed order: tw[m+i].x = psi^bitrev(m+i)
+  const u64x2 *itw;  // [N] inverse twiddles (itw[m+i].x = tw[m+i].x^-1)
 };
 
 // ---- one radix-2^R register pass over NG = 16>>R groups -------------------------------------------
@@ -54,8 +54,8 @@ __device__ __forceinline__ void fwd_pass(u64 (&x)[16], const int (&hi)[16 >> R],
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
         int idx = base + (k >> (R - u));
-        if (UNIFORM) idx = __builtin_amdgcn_readfirstlane(idx);
-        u64 w = t.tw[idx], ws = t.tws[idx];
+        const u64x2 tp = t.tw[idx];
+        const u64 w = tp.x, ws = tp.y;
         u64 &X = x[g * (1 << R) + k];
         u64 &Y = x[g * (1 << R) + (k | half)];
         if (GUARD) {
@@ -89,8 +89,8 @@ __device__ __forceinline__ void inv_pass(u64 (&x)[16], const int (&hi)[16 >> R],
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
         int idx = base + (k >> (R - u));
-        if (UNIFORM) idx = __builtin_amdgcn_readfirstlane(idx);
-        u64 w = t.itw[idx], ws = t.itws[idx];
+        const u64x2 tp = t.itw[idx];
+        const u64 w = tp.x, ws = tp.y;
         u64 &X = x[g * (1 << R) + k];
         u64 &Y = x[g * (1 << R) + (k | half)];
         u64 a = X, c = Y;
@@ -114,11 +114,20 @@ struct PassIdx {
   static constexpr int G = 1 << LOGG;
   static constexpr bool UNIFORM = (G >= 64);  // all 64 lanes of a wave share hi
   __device__ __forceinline__ static void groups(int tid, int (&hi)[NG], int (&lo)[NG]) {
+    // the wave index as a scalar: where hi is wave-uniform (G >= 64) every twiddle index then stays in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-      int p = (tid >> 6) * (64 * NG) + g * 64 + (tid & 63);
-      hi[g] = p >> LOGG;
-      lo[g] = p & (G - 1);
+      if (UNIFORM) {
+        const int pw = wave * (64 * NG) + g * 64;  // scalar part of p; the lane part cannot reach bit LOGG
+        hi[g] = pw >> LOGG;
+        lo[g] = (pw + lane) & (G - 1);
+      } else {
+        const int p = wave * (64 * NG) + g * 64 + lane;
+        hi[g] = p >> LOGG;
+        lo[g] = p & (G - 1);
+      }
     }
   }
   __device__ __forceinline__ static int elem(int hi, int lo, int k) { return (hi << (LB - S)) + (k << LOGG) + lo; }
