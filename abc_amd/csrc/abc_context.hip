@@ -206,6 +206,25 @@ static int build_context(abc_hip_ctx *c) {
       k.B_to_msk[b] = punct_mod(Bp, b, m_sk);
     }
     k.inv_B_mod_msk = invmod(prod_mod(Bp, m_sk), m_sk);
+    k.inv_B_mod_msk_s = shoup(k.inv_B_mod_msk, m_sk);
+    for (int i = 0; i < L; i++) {
+      const uint64_t q = qs[i];
+      k.ext_q[i] = mulmod(k.mtilde_mod_q[i], k.inv_punct_q[i], q);
+      k.ext_q_s[i] = shoup(k.ext_q[i], q);
+      k.flr_q[i] = mulmod(k.t_mod_q[i], k.inv_punct_q[i], q);
+      k.flr_q_s[i] = shoup(k.flr_q[i], q);
+      k.dec_q[i] = mulmod(k.tgamma_mod_q[i], k.inv_punct_q[i], q);
+      k.dec_q_s[i] = shoup(k.dec_q[i], q);
+      k.B_mod_q_s[i] = shoup(k.B_mod_q[i], q);
+    }
+    for (int j = 0; j < nBsk; j++) {
+      const uint64_t p = bsk[j];
+      k.tinvq_bsk[j] = mulmod(k.t_mod_bsk[j], k.inv_q_mod_bsk[j], p);
+      k.tinvq_bsk_s[j] = shoup(k.tinvq_bsk[j], p);
+      k.inv_q_mod_bsk_s[j] = shoup(k.inv_q_mod_bsk[j], p);
+      k.inv_mtilde_mod_bsk_s[j] = shoup(k.inv_mtilde_mod_bsk[j], p);
+    }
+    for (int b = 0; b < nB; b++) k.inv_punct_B_s[b] = shoup(k.inv_punct_B[b], Bp[b]);
     k.neg_inv_q_mod_t = negmod(invmod(prod_mod(qs, t), t), t);
     k.neg_inv_q_mod_gamma = negmod(invmod(prod_mod(qs, gamma), gamma), gamma);
     k.inv_gamma_mod_t = invmod(gamma % t, t);

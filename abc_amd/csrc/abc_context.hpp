@@ -41,6 +41,13 @@ struct DevConst {
   u64 B_to_msk[kMaxLimbs];
   u64 inv_B_mod_msk, B_mod_q[kMaxLimbs];
   u64 t_mod_q[kMaxLimbs], t_mod_bsk[kMaxLimbs];
+  // fused constants with Shoup quotients (a constant operand costs half a Barrett multiply):
+  u64 ext_q[kMaxLimbs], ext_q_s[kMaxLimbs];          // m~ * (q/q_i)^-1 mod q_i          (BEHZ extend)
+  u64 flr_q[kMaxLimbs], flr_q_s[kMaxLimbs];          // t  * (q/q_i)^-1 mod q_i          (BEHZ floor)
+  u64 tinvq_bsk[kMaxLimbs], tinvq_bsk_s[kMaxLimbs];  // t * q^-1 mod Bsk_j
+  u64 inv_q_mod_bsk_s[kMaxLimbs], inv_mtilde_mod_bsk_s[kMaxLimbs], inv_punct_B_s[kMaxLimbs];
+  u64 inv_B_mod_msk_s, B_mod_q_s[kMaxLimbs];
+  u64 dec_q[kMaxLimbs], dec_q_s[kMaxLimbs];          // t*gamma * (q/q_i)^-1 mod q_i     (decrypt)
   // BFV decryption (decrypt_scale_and_round)
   u64 tgamma_mod_q[kMaxLimbs], q_to_t[kMaxLimbs], q_to_gamma[kMaxLimbs];
   u64 neg_inv_q_mod_t, neg_inv_q_mod_gamma, inv_gamma_mod_t, gamma;

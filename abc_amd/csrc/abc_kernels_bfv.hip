@@ -48,9 +48,8 @@ __global__ __launch_bounds__(256) void k_behz_extend(DevCtx c, const u64 *in, u6
     u64 tmp[kMaxLimbs];
     u32 mt = 0;
     for (int i = 0; i < L; i++) {
-      const Mod m = c.mods[i];
-      u64 v = mul_mod(in[(p * L + i) * c.n + x], k.mtilde_mod_q[i], m);  // * m~
-      v = mul_mod(v, k.inv_punct_q[i], m);                               // * (q/q_i)^-1
+      // * m~ * (q/q_i)^-1 as one constant (canonical result, so identical to the two-step product)
+      const u64 v = mul_shoup(in[(p * L + i) * c.n + x], k.ext_q[i], k.ext_q_s[i], c.mods[i].q);
       tmp[i] = v;
       mt += (u32)v * (u32)k.q_to_mtilde[i];  // arithmetic mod 2^32
     }
@@ -63,7 +62,7 @@ __global__ __launch_bounds__(256) void k_behz_extend(DevCtx c, const u64 *in, u6
       U128 acc = mul_wide(r, k.q_mod_bsk[j]);
       add128(acc, U128{conv, 0});
       const u64 v = barrett_reduce(acc, m);
-      out[(p * nBsk + j) * c.n + x] = mul_mod(v, k.inv_mtilde_mod_bsk[j], m);
+      out[(p * nBsk + j) * c.n + x] = mul_shoup(v, k.inv_mtilde_mod_bsk[j], k.inv_mtilde_mod_bsk_s[j], m.q);
     }
   }
 }
@@ -98,26 +97,25 @@ __global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, con
     const size_t p = it >> c.logn, x = it & (c.n - 1);
     u64 tq[kMaxLimbs], fl[kMaxLimbs];
     for (int i = 0; i < L; i++) {
-      const Mod m = c.mods[i];
-      u64 v = mul_mod(dq[(p * L + i) * c.n + x], k.t_mod_q[i], m);
-      tq[i] = mul_mod(v, k.inv_punct_q[i], m);
+      tq[i] = mul_shoup(dq[(p * L + i) * c.n + x], k.flr_q[i], k.flr_q_s[i], c.mods[i].q);  // * t * (q/q_i)^-1
     }
     for (int j = 0; j < nBsk; j++) {
       const Mod m = c.mods[c.id_bsk + j];
       const u64 conv = dot_mod(L, [&](int i) { return tq[i]; }, [&](int i) { return k.q_to_bsk[j][i]; }, m);
-      const u64 xb = mul_mod(dB[(p * nBsk + j) * c.n + x], k.t_mod_bsk[j], m);
-      fl[j] = mul_mod(sub_mod(xb, conv, m.q), k.inv_q_mod_bsk[j], m);
+      // (dB*t - conv) * q^-1 = dB*(t q^-1) - conv*q^-1   (both constants carry Shoup quotients)
+      const u64 xb = mul_shoup(dB[(p * nBsk + j) * c.n + x], k.tinvq_bsk[j], k.tinvq_bsk_s[j], m.q);
+      fl[j] = sub_mod(xb, mul_shoup(conv, k.inv_q_mod_bsk[j], k.inv_q_mod_bsk_s[j], m.q), m.q);
     }
     u64 tb[kMaxLimbs];
-    for (int b2 = 0; b2 < nB; b2++) tb[b2] = mul_mod(fl[b2], k.inv_punct_B[b2], c.mods[c.id_bsk + b2]);
+    for (int b2 = 0; b2 < nB; b2++) tb[b2] = mul_shoup(fl[b2], k.inv_punct_B[b2], k.inv_punct_B_s[b2], c.mods[c.id_bsk + b2].q);
     const u64 msk_conv = dot_mod(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_msk[b2]; }, msk);
-    const u64 alpha = mul_mod(sub_mod(msk_conv, fl[nB], msk.q), k.inv_B_mod_msk, msk);
+    const u64 alpha = mul_shoup(sub_mod(msk_conv, fl[nB], msk.q), k.inv_B_mod_msk, k.inv_B_mod_msk_s, msk.q);
     const bool neg = alpha > (msk.q >> 1);
     for (int i = 0; i < L; i++) {
       const Mod m = c.mods[i];
       u64 v = dot_mod(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_q[i][b2]; }, m);
-      if (neg) v = add_mod(v, mul_mod(msk.q - alpha, k.B_mod_q[i], m), m.q);
-      else v = sub_mod(v, mul_mod(alpha, k.B_mod_q[i], m), m.q);
+      if (neg) v = add_mod(v, mul_shoup(msk.q - alpha, k.B_mod_q[i], k.B_mod_q_s[i], m.q), m.q);
+      else v = sub_mod(v, mul_shoup(alpha, k.B_mod_q[i], k.B_mod_q_s[i], m.q), m.q);
       out[(p * L + i) * c.n + x] = v;
     }
   }
@@ -301,9 +299,7 @@ __global__ __launch_bounds__(256) void k_bfv_decrypt_round(DevCtx c, const u64 *
     const size_t p = it >> c.logn, x = it & (c.n - 1);
     u64 tmp[kMaxLimbs];
     for (int i = 0; i < c.L; i++) {
-      const Mod m = c.mods[i];
-      const u64 v = mul_mod(phase[(p * c.L + i) * c.n + x], k.tgamma_mod_q[i], m);
-      tmp[i] = mul_mod(v, k.inv_punct_q[i], m);
+      tmp[i] = mul_shoup(phase[(p * c.L + i) * c.n + x], k.dec_q[i], k.dec_q_s[i], c.mods[i].q);  // * t*gamma*(q/q_i)^-1
     }
     u64 vt = dot_mod(c.L, [&](int i) { return tmp[i]; }, [&](int i) { return k.q_to_t[i]; }, mt);
     u64 vg = dot_mod(c.L, [&](int i) { return tmp[i]; }, [&](int i) { return k.q_to_gamma[i]; }, mg);
