@@ -179,15 +179,9 @@ template <> struct Sched<14> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 =
 //                              bit-reversed order) held in register slot r (r is a compile-time
 //                              constant after unrolling, so callers may index register arrays with it)
 // The final register layout is PassIdx<LB, LB-2, 2>: slot r = 4g+k holds element 4*(tid + T*g) + k.
-struct NoHook {
-  __device__ __forceinline__ void operator()() const {}
-};
-
-// `before_last` runs right before the final register pass (after its barrier): the place to issue the
-// global loads of a persistent workgroup's NEXT limb, so their latency hides under the last pass and the stores.
-template <int LB, bool GUARD = true, class Load, class Store, class Hook = NoHook>
+template <int LB, bool GUARD = true, class Load, class Store>
 __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
-                                              int b, Hook before_last = Hook()) {
+                                              int b) {
   using SC = Sched<LB>;
   const int tid = threadIdx.x;
   const u64 q = m.q, two_q = m.two_q;
@@ -228,7 +222,6 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     using P = PassIdx<LB, S, R>;
     int hi[P::NG], lo[P::NG];
     P::groups(tid, hi, lo);
-    if constexpr (SC::R3 == 0) before_last();
     lds_load<LB, S, R>(lds, x, hi, lo);
     fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
     if constexpr (SC::R3 == 0) {
@@ -247,7 +240,6 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     using P = PassIdx<LB, S, R>;
     int hi[P::NG], lo[P::NG];
     P::groups(tid, hi, lo);
-    before_last();
     lds_load<LB, S, R>(lds, x, hi, lo);
     fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
 #pragma unroll
@@ -262,9 +254,9 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
 //                              as the forward transform's final one
 // store(r, i, v)               v in [0,2q): coefficient i BEFORE the N^-1 scaling (caller scales:
 //                              for a sub-block the scaling belongs to the final strided pass)
-template <int LB, class Load, class Store, class Hook = NoHook>
+template <int LB, class Load, class Store>
 __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
-                                              int b, Hook before_last = Hook()) {
+                                              int b) {
   using SC = Sched<LB>;
   const int tid = threadIdx.x;
   const u64 q = m.q, two_q = m.two_q;
@@ -315,7 +307,6 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
     using P = PassIdx<LB, S, R>;
     int hi[P::NG], lo[P::NG];
     P::groups(tid, hi, lo);
-    before_last();
     lds_load<LB, S, R>(lds, x, hi, lo);
     inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
 #pragma unroll
@@ -323,20 +314,6 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) store(g * (1 << R) + k, P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
   }
-}
-
-// element held by register slot r in the first forward pass (= last inverse pass)
-template <int LB>
-__device__ __forceinline__ int first_fwd_elem(int r) {
-  using P = PassIdx<LB, 0, Sched<LB>::R0>;
-  constexpr int R = Sched<LB>::R0;
-  const int p = threadIdx.x + P::T * (r >> R);
-  return P::elem(p >> P::LOGG, p & (P::G - 1), r & ((1 << R) - 1));
-}
-// element held by register slot r = 4g+k in the last forward pass (= first inverse pass): 4*(256 w + 64 g + lane) + k
-template <int LB>
-__device__ __forceinline__ int last_fwd_elem(int r) {
-  return ((((int)threadIdx.x >> 6) * 256 + (r >> 2) * 64 + ((int)threadIdx.x & 63)) << 2) + (r & 3);
 }
 
 // lazily reduced [0,4q) -> [0,q)
