@@ -69,6 +69,10 @@ static Mod make_mod(uint64_t q, int logn, bool ntt) {
     const uint64_t n = 1ull << logn;
     m.inv_n = invmod(n % q, q);
     m.inv_n_s = shoup(m.inv_n, q);
+    if (fp_ok(m.bits)) {
+      m.inv_n_c = m.inv_n > q / 2 ? -(double)(q - m.inv_n) : (double)m.inv_n;
+      m.inv_n_cq = m.inv_n_c / m.qd;
+    }
   }
   return m;
 }
@@ -92,6 +96,17 @@ static void fill_twiddles(uint64_t q, int logn, uint64_t *dst /*[2][N][2]*/) {
   for (size_t i = 0; i < n; i++) {
     fwd[2 * i + 1] = shoup(fwd[2 * i], q);
     inv[2 * i + 1] = shoup(inv[2 * i], q);
+  }
+}
+
+// fp64 twin of one modulus' twiddle table: {w centred into (-q/2, q/2], w / q} (both exact-operand roundings)
+static void fill_fp_twiddles(uint64_t q, size_t n, const uint64_t *src /*[2][N][2]*/, double *dst) {
+  const double qd = (double)q;
+  for (size_t i = 0; i < 2 * n; i++) {
+    const uint64_t w = src[2 * i];
+    const double wc = w > q / 2 ? -(double)(q - w) : (double)w;
+    dst[2 * i] = wc;
+    dst[2 * i + 1] = wc / qd;
   }
 }
 
@@ -128,10 +143,13 @@ static int build_context(abc_hip_ctx *c) {
   const int id_bsk = K, id_gamma = K + c->nBsk, id_t = K + c->nBsk + 1;
   c->h_mods.clear();
   std::vector<uint64_t> h_tw((size_t)nmods * 4 * N, 0);
+  std::vector<double> h_ftw((size_t)nmods * 4 * N, 0.0);
   for (int i = 0; i < nmods; i++) {
     const bool ntt = !(bfv && i == id_gamma);
     c->h_mods.push_back(make_mod(c->mod_values[i], logn, ntt));
     if (ntt) fill_twiddles(c->mod_values[i], logn, h_tw.data() + (size_t)i * 4 * N);
+    if (ntt && fp_ok(c->h_mods.back().bits))
+      fill_fp_twiddles(c->mod_values[i], N, h_tw.data() + (size_t)i * 4 * N, h_ftw.data() + (size_t)i * 4 * N);
   }
 
   // ---- key / modulus switching constants ----
@@ -236,6 +254,9 @@ static int build_context(abc_hip_ctx *c) {
   ABC_HIP_CHECK(hipMemcpy(c->d_mods, c->h_mods.data(), nmods * sizeof(Mod), hipMemcpyHostToDevice));
   ABC_HIP_CHECK(hipMalloc(&c->d_tw, h_tw.size() * 8));
   ABC_HIP_CHECK(hipMemcpy(c->d_tw, h_tw.data(), h_tw.size() * 8, hipMemcpyHostToDevice));
+  ABC_HIP_CHECK(hipMalloc(&c->d_ftw, h_ftw.size() * 8));
+  ABC_HIP_CHECK(hipMemcpy(c->d_ftw, h_ftw.data(), h_ftw.size() * 8, hipMemcpyHostToDevice));
+  c->use_fp = (std::getenv("ABC_HIP_NO_FP64") == nullptr);
   ABC_HIP_CHECK(hipMalloc(&c->d_cst, sizeof(DevConst)));
   ABC_HIP_CHECK(hipMemcpy(c->d_cst, &k, sizeof(DevConst), hipMemcpyHostToDevice));
   if (bfv) {
@@ -243,7 +264,7 @@ static int build_context(abc_hip_ctx *c) {
     ABC_HIP_CHECK(hipMemcpy(c->d_slot_map, slot_map.data(), N * 4, hipMemcpyHostToDevice));
   }
   DevCtx &dc = c->dc;
-  dc.mods = c->d_mods; dc.tw = c->d_tw; dc.cst = c->d_cst; dc.slot_map = c->d_slot_map;
+  dc.mods = c->d_mods; dc.tw = c->d_tw; dc.ftw = c->d_ftw; dc.cst = c->d_cst; dc.slot_map = c->d_slot_map;
   dc.logn = logn; dc.n = (int)N; dc.K = K; dc.L = L;
   dc.id_bsk = id_bsk; dc.id_t = id_t; dc.id_gamma = id_gamma; dc.id_mtilde = -1;
   return 0;
@@ -478,7 +499,7 @@ void abc_hip_ctx_destroy(abc_hip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  (void)hipFree(c->d_mods); (void)hipFree(c->d_tw); (void)hipFree(c->d_cst); (void)hipFree(c->d_slot_map);
+  (void)hipFree(c->d_mods); (void)hipFree(c->d_tw); (void)hipFree(c->d_ftw); (void)hipFree(c->d_cst); (void)hipFree(c->d_slot_map);
   (void)hipFree(c->d_sk); (void)hipFree(c->d_pk); (void)hipFree(c->d_relin);
   for (auto &kv : c->d_galois) (void)hipFree(kv.second);
   (void)hipFree(c->ws);

@@ -57,6 +57,7 @@ struct DevConst {
 struct DevCtx {
   const Mod *mods;      // [nmods]
   const u64 *tw;        // [nmods][2][N][2]: forward {w, Shoup} pairs, then inverse pairs
+  const double *ftw;    // same shape, fp64 twin {w centred, w / q}; filled for primes < 2^50 only
   const DevConst *cst;  //
   const u32 *slot_map;  // [N] BatchEncoder index map (BFV)
   int logn, n;
@@ -69,6 +70,14 @@ __device__ __forceinline__ NttTable ntt_table(const DevCtx &c, int mid) {
   NttTable t;
   t.tw = reinterpret_cast<const u64x2 *>(b);
   t.itw = reinterpret_cast<const u64x2 *>(b + 2 * (size_t)c.n);
+  return t;
+}
+
+__device__ __forceinline__ FpTable fp_table(const DevCtx &c, int mid) {
+  const double *b = c.ftw + (size_t)mid * 4 * c.n;
+  FpTable t;
+  t.tw = reinterpret_cast<const f64x2 *>(b);
+  t.itw = reinterpret_cast<const f64x2 *>(b + 2 * (size_t)c.n);
   return t;
 }
 
@@ -94,6 +103,8 @@ struct abc_hip_ctx {
   abc::DevConst h_cst{};
   abc::Mod *d_mods = nullptr;
   uint64_t *d_tw = nullptr;
+  double *d_ftw = nullptr;
+  bool use_fp = true;  // fp64 transforms for primes < 2^50 (ABC_HIP_NO_FP64=1 forces the integer path)
   abc::DevConst *d_cst = nullptr;
   uint32_t *d_slot_map = nullptr;
   // keys (device)

@@ -38,6 +38,34 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv(DevCtx c, u64 *data,
       S0, b);
 }
 
+// fp64 variants (every prime of the launch below 2^50, whole transform in one block): same memory format, the
+// conversion u64 <-> double happens in the load / store functors.
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd_fp(DevCtx c, u64 *data, LimbMap map, int nl) {
+  __shared__ double lds[lds_words(LB)];
+  const size_t limb = blockIdx.x;
+  const int mid = map.id[limb % nl];
+  const Mod m = c.mods[mid];
+  const FpTable t = fp_table(c, mid);
+  u64 *base = data + limb * (size_t)c.n;
+  ntt_fwd_block_a<LB, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(base[i]); }, [&](int, int i, double v) { base[i] = fp_to_canon(v, m.qd, m.qinv); },
+      t, m, 0, 0);
+}
+
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv_fp(DevCtx c, u64 *data, LimbMap map, int nl) {
+  __shared__ double lds[lds_words(LB)];
+  const size_t limb = blockIdx.x;
+  const int mid = map.id[limb % nl];
+  const Mod m = c.mods[mid];
+  const FpTable t = fp_table(c, mid);
+  u64 *base = data + limb * (size_t)c.n;
+  ntt_inv_block_a<LB, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(base[i]); },
+      [&](int, int i, double v) { base[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv); }, t, m, 0, 0);
+}
+
 // first R stages of a 2^logn-point forward transform, straight through HBM (coalesced: lane = p)
 template <int R>
 __global__ __launch_bounds__(256) void k_ntt_fwd_strided(DevCtx c, u64 *data, LimbMap map, int nl) {
@@ -109,9 +137,16 @@ static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size
   dim3 grid((unsigned)(total_limbs << S0)), block((1 << LB) / 16);
   // every limb of the launch must allow the unguarded butterflies; the strided pre-pass (S0 > 0) already
   // spent part of the headroom, keep the guard there
-  bool guard = (S0 != 0);
-  for (int j = 0; j < nl; j++) guard = guard || !unguarded_ok(c->h_mods[map.id[j]].bits);
-  if (fwd && guard)
+  bool guard = (S0 != 0), fp = (S0 == 0) && c->use_fp;
+  for (int j = 0; j < nl; j++) {
+    guard = guard || !unguarded_ok(c->h_mods[map.id[j]].bits);
+    fp = fp && fp_ok(c->h_mods[map.id[j]].bits);
+  }
+  if (fp && fwd)
+    hipLaunchKernelGGL(k_ntt_fwd_fp<LB>, grid, block, 0, c->stream, c->dc, d, map, nl);
+  else if (fp)
+    hipLaunchKernelGGL(k_ntt_inv_fp<LB>, grid, block, 0, c->stream, c->dc, d, map, nl);
+  else if (fwd && guard)
     hipLaunchKernelGGL((k_ntt_fwd<LB, true>), grid, block, 0, c->stream, c->dc, d, map, nl, S0);
   else if (fwd)
     hipLaunchKernelGGL((k_ntt_fwd<LB, false>), grid, block, 0, c->stream, c->dc, d, map, nl, S0);

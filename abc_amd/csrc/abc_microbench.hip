@@ -128,6 +128,13 @@ __global__ __launch_bounds__(256) void k_mb_instr(u64 *sink, int iters) {
     if (WHICH == 7) ABC_ASM8("v_cndmask_b32 v12, v10, v11, vcc");
     if (WHICH == 8) ABC_ASM8("v_mad_u32_u24 v12, v10, v11, v12");
     if (WHICH == 9) ABC_ASM8("v_mul_hi_u32_u24 v12, v10, v11");
+    if (WHICH == 10) ABC_ASM8("v_fma_f64 v[12:13], v[10:11], v[10:11], v[12:13]");
+    if (WHICH == 11) ABC_ASM8("v_mul_f64 v[12:13], v[10:11], v[10:11]");
+    if (WHICH == 12) ABC_ASM8("v_add_f64 v[12:13], v[10:11], v[12:13]");
+    if (WHICH == 13) ABC_ASM8("v_rndne_f64 v[12:13], v[10:11]");
+    if (WHICH == 14) ABC_ASM8("v_cvt_f64_u32 v[12:13], v10");
+    if (WHICH == 15) ABC_ASM8("v_and_b32 v12, v10, v11");
+    if (WHICH == 16) ABC_ASM8("v_pk_add_f32 v[12:13], v[10:11], v[12:13]");
   }
   u32 r;
   asm volatile("v_mov_b32 %0, v12" : "=v"(r)::"v12");
@@ -143,7 +150,7 @@ int microbench_instr(abc_hip_ctx *c, int which, int iters, double *ms) {
     ABC_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     switch (which) {
 #define ABC_CASE(W) case W: hipLaunchKernelGGL(k_mb_instr<W>, dim3(blocks), dim3(threads), 0, c->stream, sink, iters); break;
-      ABC_CASE(0) ABC_CASE(1) ABC_CASE(2) ABC_CASE(3) ABC_CASE(4) ABC_CASE(5) ABC_CASE(6) ABC_CASE(7) ABC_CASE(8) ABC_CASE(9)
+      ABC_CASE(0) ABC_CASE(1) ABC_CASE(2) ABC_CASE(3) ABC_CASE(4) ABC_CASE(5) ABC_CASE(6) ABC_CASE(7) ABC_CASE(8) ABC_CASE(9) ABC_CASE(10) ABC_CASE(11) ABC_CASE(12) ABC_CASE(13) ABC_CASE(14) ABC_CASE(15) ABC_CASE(16)
       default: set_error("microbench: unknown instruction probe"); return 1;
     }
     ABC_HIP_CHECK(hipGetLastError());
@@ -231,6 +238,31 @@ __global__ __launch_bounds__(256) void k_mb_bfly_asm(const Mod *mods, u64 *sink,
   sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// fp64 butterfly for primes below 2^50: v = y*w - rint(y*w/q)*q through two error-free FMA steps (no corrections,
+// signed lazy residues), then X = a + v, Y = a - v.  8 DP instructions.
+__global__ __launch_bounds__(256) void k_mb_bfly_fp(const Mod *mods, u64 *sink, int iters, double w, double wq) {
+  const double q = mods[1].qd;
+  double x[4], y[4];
+  for (int k = 0; k < 4; k++) { x[k] = threadIdx.x + 17 * k + 1; y[k] = blockIdx.x + 31 * k + 5; }
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double a = x[k];
+      const double v = fp_mul_lazy(y[k], w, wq, q);
+      x[k] = a + v;
+      y[k] = a - v;
+    }
+    if ((i & 7) == 7) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {  // keep the residues bounded (costs 6/64 extra instructions per butterfly)
+        x[k] = __builtin_fma(-__builtin_rint(x[k] * mods[1].qinv), q, x[k]);
+        y[k] = __builtin_fma(-__builtin_rint(y[k] * mods[1].qinv), q, y[k]);
+      }
+    }
+  }
+  sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = (u64)(long long)(x[0] + x[1] + x[2] + x[3] + y[0] + y[1] + y[2] + y[3]);
+}
+
 int microbench_bfly(abc_hip_ctx *c, int which, int iters, double *ms) {
   const int blocks = 256 * 4, threads = 256;
   if (ensure_workspace(c, (size_t)blocks * threads * 8)) return 1;
@@ -241,7 +273,11 @@ int microbench_bfly(abc_hip_ctx *c, int which, int iters, double *ms) {
     ABC_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     if (which == 0)
       hipLaunchKernelGGL(k_mb_bfly_cpp, dim3(blocks), dim3(threads), 0, c->stream, c->d_mods, sink, iters, w, ws);
-    else
+    else if (which == 2) {
+      const u64 q1 = c->h_mods[1].q, w1 = q1 / 3 + 12345;
+      hipLaunchKernelGGL(k_mb_bfly_fp, dim3(blocks), dim3(threads), 0, c->stream, c->d_mods, sink, iters, (double)w1,
+                         (double)w1 / (double)q1);
+    } else
       hipLaunchKernelGGL(k_mb_bfly_asm, dim3(blocks), dim3(threads), 0, c->stream, c->d_mods, sink, iters, w, ws);
     ABC_HIP_CHECK(hipGetLastError());
     ABC_HIP_CHECK(hipEventRecord(c->ev1, c->stream));

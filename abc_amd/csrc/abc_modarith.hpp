@@ -33,6 +33,8 @@ struct Mod {
   u64 inv_n_s; // Shoup quotient of inv_n
   double qd;   // (double) q            (fp64 fast path, primes < 2^50 only)
   double qinv; // 1.0 / q
+  double inv_n_c;   // N^-1 mod q centred into (-q/2, q/2]   (fp64 path)
+  double inv_n_cq;  // inv_n_c / q
 };
 
 struct U128 {

@@ -31,17 +31,136 @@ struct NttTable {
   const u64x2 *tw;   // [N] forward twiddles {w, Shoup quotient}, bit-reversed order: tw[m+i].x = psi^bitrev(m+i)
   const u64x2 *itw;  // [N] inverse twiddles (itw[m+i].x = tw[m+i].x^-1)
 };
+// fp64 twin of the table for primes below 2^50: {w centred into (-q/2, q/2], w / q}
+struct alignas(16) f64x2 {
+  double x, y;
+};
+struct FpTable {
+  const f64x2 *tw, *itw;
+};
 
-// ---- one radix-2^R register pass over NG = 16>>R groups -------------------------------------------
-// Forward (CT): stages S..S+R-1 of the block-local transform.
+// ---- fp64 residue arithmetic (primes < 2^50) ------------------------------------------------------------
+// Residues are integer-valued doubles, signed and lazily reduced.  Every operation below is exact as long as
+// the magnitudes stay below 2^53, so results are the same integers mod q that the 64-bit path produces; only the
+// quotient estimate c is approximate, which changes WHICH representative comes out, never its residue class.
+//   v = y*w - c*q,  c = rint(y * (w/q)):  h = fl(y*w), l = y*w - h (FMA, exact), d = h - c*q (FMA, exact because
+//   |d| < 2^53 and d is a multiple of ulp(h) or an integer), v = d + l.
+//   |c - y*w/q| <= 1/2 + |y| * |w/q| * 2^-52  and |w| <= q/2, so  |v| <= q/2 + |y| * q * 2^-53:
+//   one stage grows a bound Y on |value| to at most Y (1 + q 2^-53) + q/2.
+// Primes of 49 and 50 bits (q 2^-53 >= 1/16) are re-centred at the start of every register pass (FpK::red),
+// smaller ones need no reduction inside a forward transform (2^50 (1 + 2^-5)^14 + 7.7 q < 2^52).
+// 8 DP instructions per butterfly instead of 16 integer ones, no carry chains (no VCC hazards), measured
+// 3.2 T butterflies/s against 2.2 T/s in isolation (tools/microbench.py probes 200/202).
+struct FpK {
+  double q, qinv;
+  bool red;  // 49- and 50-bit primes
+};
+#pragma clang fp contract(off)
+__device__ __forceinline__ double fp_mul_lazy(double y, double w, double wq, double q) {
+  const double h = y * w;
+  const double l = __builtin_fma(y, w, -h);
+  const double c = __builtin_rint(y * wq);
+  return __builtin_fma(-c, q, h) + l;
+}
+// centred representative: |result| <= q/2 (+ |x| q 2^-105, nothing)
+__device__ __forceinline__ double fp_centre(double x, double q, double qinv) {
+  return __builtin_fma(-__builtin_rint(x * qinv), q, x);
+}
+// exact conversions: u64 below 2^52 <-> integer-valued double
+__device__ __forceinline__ double fp_from_u64(u64 v) {
+  return __longlong_as_double((long long)(v | 0x4330000000000000ull)) - 4503599627370496.0;
+}
+// any lazy value -> canonical [0, q) as u64: centre, add q where negative (sign mask, no VCC), strip the exponent
+__device__ __forceinline__ u64 fp_to_canon(double x, double q, double qinv) {
+  double r = fp_centre(x, q, qinv);
+  const u32 neg = (u32)((int)(u32)((u64)__double_as_longlong(r) >> 32) >> 31);
+  const u64 qb = (u64)__double_as_longlong(q);
+  const u64 add = ((u64)((u32)(qb >> 32) & neg) << 32) | (u64)((u32)qb & neg);
+  r += __longlong_as_double((long long)add);
+  return (u64)__double_as_longlong(r + 4503599627370496.0) & 0x000fffffffffffffull;
+}
+// any lazy value -> a non-negative representative in [q/2, 3q/2] as u64 (for consumers that reduce anyway)
+__device__ __forceinline__ u64 fp_to_lazy(double x, double q, double qinv) {
+  const double r = fp_centre(x, q, qinv);
+  return (u64)__double_as_longlong(r + (4503599627370496.0 + q)) & 0x000fffffffffffffull;
+}
+__host__ __device__ __forceinline__ bool fp_ok(u32 bits) { return bits <= 50; }
+
+// ---- arithmetic policies of the register passes ---------------------------------------------------------
+// Integer (Harvey lazy) butterflies.
 // GUARD = false: no per-stage correction of X and the cheaper quotient estimate (mul_shoup_lazy4, product in
 // [0,4q)); every stage then adds at most 4q to a value, so after all logN <= 14 stages of a block a canonical
 // input stays below (4*14 + 1) q = 57q -- usable whenever that fits 64 bits (q <= 57 bits), which holds for every
 // SEAL default prime up to N = 32768 and for the CKKS chains here; the 61-bit BEHZ primes (and 58..60-bit user
-// primes) take the guarded form.
-template <int LB, int S, int R, bool UNIFORM, bool GUARD = true>
-__device__ __forceinline__ void fwd_pass(u64 (&x)[16], const int (&hi)[16 >> R], const NttTable &t, u64 q, u64 two_q,
-                                         int S0, int b) {
+// primes) take the guarded form.  Inverse: inputs/outputs in [0,2q).
+template <bool GUARD>
+struct IntArith {
+  using E = u64;
+  using TW = u64x2;
+  using Table = NttTable;
+  struct K {
+    u64 q, two_q;
+  };
+  __device__ __forceinline__ static K consts(const Mod &m) { return K{m.q, m.two_q}; }
+  __device__ __forceinline__ static void fwd(E &X, E &Y, const TW tp, const K &k) {
+    if (GUARD) {
+      const u64 a = csub(X, k.two_q);
+      const u64 v = mul_shoup_lazy(Y, tp.x, tp.y, k.q);
+      X = a + v;
+      Y = a + k.two_q - v;
+    } else {
+      const u64 a = X;
+      const u64 v = mul_shoup_lazy4(Y, tp.x, tp.y, k.q);
+      X = a + v;
+      Y = a + (k.two_q << 1) - v;
+    }
+  }
+  __device__ __forceinline__ static void inv(E &X, E &Y, const TW tp, const K &k) {
+    const u64 a = X, c = Y;
+    X = csub(a + c, k.two_q);
+    Y = mul_shoup_lazy(a + k.two_q - c, tp.x, tp.y, k.q);
+  }
+  template <int PASS> __device__ __forceinline__ static void fwd_begin(E (&)[16], const K &) {}
+  template <int PASS> __device__ __forceinline__ static void inv_begin(E (&)[16], const K &) {}
+};
+
+// fp64 butterflies.  Forward: X = a + v, Y = a - v.  Inverse: X = a + b (doubles every stage: 16x per pass, so
+// every pass after the first starts by re-centring; the first one too for 49/50-bit primes, whose (a - b) may not
+// exceed 8q), Y = (a - b) w.
+struct FpArith {
+  using E = double;
+  using TW = f64x2;
+  using Table = FpTable;
+  using K = FpK;
+  __device__ __forceinline__ static K consts(const Mod &m) { return K{m.qd, m.qinv, m.bits >= 49}; }
+  __device__ __forceinline__ static void fwd(E &X, E &Y, const TW tp, const K &k) {
+    const double a = X;
+    const double v = fp_mul_lazy(Y, tp.x, tp.y, k.q);
+    X = a + v;
+    Y = a - v;
+  }
+  __device__ __forceinline__ static void inv(E &X, E &Y, const TW tp, const K &k) {
+    const double a = X, c = Y;
+    X = a + c;
+    Y = fp_mul_lazy(a - c, tp.x, tp.y, k.q);
+  }
+  __device__ __forceinline__ static void centre16(E (&x)[16], const K &k) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = fp_centre(x[r], k.q, k.qinv);
+  }
+  template <int PASS> __device__ __forceinline__ static void fwd_begin(E (&x)[16], const K &k) {
+    if (PASS > 0 && k.red) centre16(x, k);  // workgroup-uniform branch
+  }
+  template <int PASS> __device__ __forceinline__ static void inv_begin(E (&x)[16], const K &k) {
+    if (PASS > 0 || k.red) centre16(x, k);
+  }
+};
+
+// ---- one radix-2^R register pass over NG = 16>>R groups -------------------------------------------
+// Forward (CT): stages S..S+R-1 of the block-local transform.
+template <class A, int LB, int S, int R>
+__device__ __forceinline__ void fwd_pass(typename A::E (&x)[16], const int (&hi)[16 >> R], const typename A::Table &t,
+                                         const typename A::K &kk, int S0, int b) {
   constexpr int NG = 16 >> R;
 #pragma unroll
   for (int u = 0; u < R; u++) {
@@ -54,30 +173,16 @@ __device__ __forceinline__ void fwd_pass(u64 (&x)[16], const int (&hi)[16 >> R],
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
         int idx = base + (k >> (R - u));
-        const u64x2 tp = t.tw[idx];
-        const u64 w = tp.x, ws = tp.y;
-        u64 &X = x[g * (1 << R) + k];
-        u64 &Y = x[g * (1 << R) + (k | half)];
-        if (GUARD) {
-          const u64 a = csub(X, two_q);
-          const u64 v = mul_shoup_lazy(Y, w, ws, q);
-          X = a + v;
-          Y = a + two_q - v;
-        } else {
-          const u64 a = X;
-          const u64 v = mul_shoup_lazy4(Y, w, ws, q);
-          X = a + v;
-          Y = a + (two_q << 1) - v;
-        }
+        A::fwd(x[g * (1 << R) + k], x[g * (1 << R) + (k | half)], t.tw[idx], kk);
       }
     }
   }
 }
 
-// Inverse (GS): stages S+R-1 .. S (reverse order). Inputs/outputs in [0,2q).
-template <int LB, int S, int R, bool UNIFORM>
-__device__ __forceinline__ void inv_pass(u64 (&x)[16], const int (&hi)[16 >> R], const NttTable &t, u64 q, u64 two_q,
-                                         int S0, int b) {
+// Inverse (GS): stages S+R-1 .. S (reverse order).
+template <class A, int LB, int S, int R>
+__device__ __forceinline__ void inv_pass(typename A::E (&x)[16], const int (&hi)[16 >> R], const typename A::Table &t,
+                                         const typename A::K &kk, int S0, int b) {
   constexpr int NG = 16 >> R;
 #pragma unroll
   for (int u = R - 1; u >= 0; u--) {
@@ -89,13 +194,7 @@ __device__ __forceinline__ void inv_pass(u64 (&x)[16], const int (&hi)[16 >> R],
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
         int idx = base + (k >> (R - u));
-        const u64x2 tp = t.itw[idx];
-        const u64 w = tp.x, ws = tp.y;
-        u64 &X = x[g * (1 << R) + k];
-        u64 &Y = x[g * (1 << R) + (k | half)];
-        u64 a = X, c = Y;
-        X = csub(a + c, two_q);
-        Y = mul_shoup_lazy(a + two_q - c, w, ws, q);
+        A::inv(x[g * (1 << R) + k], x[g * (1 << R) + (k | half)], t.itw[idx], kk);
       }
     }
   }
@@ -133,16 +232,16 @@ struct PassIdx {
   __device__ __forceinline__ static int elem(int hi, int lo, int k) { return (hi << (LB - S)) + (k << LOGG) + lo; }
 };
 
-template <int LB, int S, int R>
-__device__ __forceinline__ void lds_load(const u64 *lds, u64 (&x)[16], const int (&hi)[16 >> R], const int (&lo)[16 >> R]) {
+template <int LB, int S, int R, class E>
+__device__ __forceinline__ void lds_load(const E *lds, E (&x)[16], const int (&hi)[16 >> R], const int (&lo)[16 >> R]) {
   using P = PassIdx<LB, S, R>;
 #pragma unroll
   for (int g = 0; g < P::NG; g++)
 #pragma unroll
     for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = lds[lds_pad(P::elem(hi[g], lo[g], k))];
 }
-template <int LB, int S, int R>
-__device__ __forceinline__ void lds_store(u64 *lds, const u64 (&x)[16], const int (&hi)[16 >> R], const int (&lo)[16 >> R]) {
+template <int LB, int S, int R, class E>
+__device__ __forceinline__ void lds_store(E *lds, const E (&x)[16], const int (&hi)[16 >> R], const int (&lo)[16 >> R]) {
   using P = PassIdx<LB, S, R>;
 #pragma unroll
   for (int g = 0; g < P::NG; g++)
@@ -179,13 +278,13 @@ template <> struct Sched<14> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 =
 //                              bit-reversed order) held in register slot r (r is a compile-time
 //                              constant after unrolling, so callers may index register arrays with it)
 // The final register layout is PassIdx<LB, LB-2, 2>: slot r = 4g+k holds element 4*(tid + T*g) + k.
-template <int LB, bool GUARD = true, class Load, class Store>
-__device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
-                                              int b) {
+template <int LB, class A, class Load, class Store>
+__device__ __forceinline__ void ntt_fwd_block_a(typename A::E *lds, Load load, Store store, const typename A::Table &t,
+                                                const Mod &m, int S0, int b) {
   using SC = Sched<LB>;
   const int tid = threadIdx.x;
-  const u64 q = m.q, two_q = m.two_q;
-  u64 x[16];
+  const typename A::K kk = A::consts(m);
+  typename A::E x[16];
   {  // pass 0: global -> regs -> LDS
     constexpr int S = 0, R = SC::R0;
     using P = PassIdx<LB, S, R>;
@@ -195,7 +294,7 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
-    fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
+    fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
   }
   block_sync_lds();
@@ -205,7 +304,8 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     int hi[P::NG], lo[P::NG];
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
-    fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
+    A::template fwd_begin<1>(x, kk);
+    fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     if constexpr (SC::R3 == 0 && SC::R2 == 0) {
 #pragma unroll
       for (int g = 0; g < P::NG; g++)
@@ -223,7 +323,8 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     int hi[P::NG], lo[P::NG];
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
-    fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
+    A::template fwd_begin<2>(x, kk);
+    fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     if constexpr (SC::R3 == 0) {
 #pragma unroll
       for (int g = 0; g < P::NG; g++)
@@ -241,7 +342,8 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
     int hi[P::NG], lo[P::NG];
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
-    fwd_pass<LB, S, R, P::UNIFORM, GUARD>(x, hi, t, q, two_q, S0, b);
+    A::template fwd_begin<3>(x, kk);
+    fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
 #pragma unroll
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
@@ -249,18 +351,24 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
   }
 }
 
+template <int LB, bool GUARD = true, class Load, class Store>
+__device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
+                                              int b) {
+  ntt_fwd_block_a<LB, IntArith<GUARD>>(lds, load, store, t, m, S0, b);
+}
+
 // ---- inverse block transform -----------------------------------------------------------------------
 // load(r, i)  -> u64 in [0,2q)  input slot i (block-local, bit-reversed order); same register layout
 //                              as the forward transform's final one
 // store(r, i, v)               v in [0,2q): coefficient i BEFORE the N^-1 scaling (caller scales:
 //                              for a sub-block the scaling belongs to the final strided pass)
-template <int LB, class Load, class Store>
-__device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
-                                              int b) {
+template <int LB, class A, class Load, class Store>
+__device__ __forceinline__ void ntt_inv_block_a(typename A::E *lds, Load load, Store store, const typename A::Table &t,
+                                                const Mod &m, int S0, int b) {
   using SC = Sched<LB>;
   const int tid = threadIdx.x;
-  const u64 q = m.q, two_q = m.two_q;
-  u64 x[16];
+  const typename A::K kk = A::consts(m);
+  typename A::E x[16];
   constexpr int SA = SC::R0, SB = SC::R0 + SC::R1, SCc = SC::R0 + SC::R1 + SC::R2;
   if constexpr (SC::R3 != 0) {
     constexpr int S = SCc, R = SC::R3;
@@ -271,7 +379,8 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
-    inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    A::template inv_begin<0>(x, kk);
+    inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
     wave_sync();  // all passes but the last are local to a wave
   }
@@ -288,7 +397,8 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
 #pragma unroll
         for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
     }
-    inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    A::template inv_begin<(SC::R3 != 0 ? 1 : 0)>(x, kk);
+    inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
     wave_sync();
   }
@@ -298,7 +408,8 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
     int hi[P::NG], lo[P::NG];
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
-    inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    A::template inv_begin<(SC::R3 != 0 ? 2 : 1)>(x, kk);
+    inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
     block_sync_lds();
   }
@@ -308,12 +419,19 @@ __device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, 
     int hi[P::NG], lo[P::NG];
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
-    inv_pass<LB, S, R, P::UNIFORM>(x, hi, t, q, two_q, S0, b);
+    A::template inv_begin<(SC::R3 != 0 ? 3 : 2)>(x, kk);
+    inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
 #pragma unroll
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) store(g * (1 << R) + k, P::elem(hi[g], lo[g], k), x[g * (1 << R) + k]);
   }
+}
+
+template <int LB, class Load, class Store>
+__device__ __forceinline__ void ntt_inv_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
+                                              int b) {
+  ntt_inv_block_a<LB, IntArith<true>>(lds, load, store, t, m, S0, b);
 }
 
 // lazily reduced [0,4q) -> [0,q)

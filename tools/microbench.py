@@ -22,7 +22,9 @@ def main():
         print("%-20s %8.3f ms  %10.1f Gop/s" % (name, ms, ops / ms / 1e6), flush=True)
     # raw instruction issue rates: 1024 workgroups x 4 waves, 8 instructions per iteration
     INSTR = {100: "v_mad_u64_u32", 101: "v_mul_lo_u32", 102: "v_mul_hi_u32", 103: "v_mul_u32_u24", 104: "v_add_u32",
-             105: "v_lshl_add_u64", 106: "v_add_co_u32", 107: "v_cndmask_b32", 108: "v_mad_u32_u24", 109: "v_mul_hi_u32_u24"}
+             105: "v_lshl_add_u64", 106: "v_add_co_u32", 107: "v_cndmask_b32", 108: "v_mad_u32_u24", 109: "v_mul_hi_u32_u24",
+             110: "v_fma_f64", 111: "v_mul_f64", 112: "v_add_f64", 113: "v_rndne_f64", 114: "v_cvt_f64_u32", 115: "v_and_b32",
+             116: "v_pk_add_f32"}
     it = 8192
     for which, name in INSTR.items():
         ms = g.microbench(which, it)
@@ -32,7 +34,7 @@ def main():
         print("%-20s %8.3f ms  %6.2f cycles per wave-instruction (if 2.4 GHz)" % (name, ms, cyc), flush=True)
     # unguarded butterfly: compiler output vs a hand-scheduled 16-instruction sequence (4 butterflies per iteration)
     it = 4096
-    for which, name in ((200, "butterfly_cpp"), (201, "butterfly_asm")):
+    for which, name in ((200, "butterfly_cpp"), (201, "butterfly_asm"), (202, "butterfly_fp64")):
         ms = g.microbench(which, it)
         cyc = ms * 1e-3 * 2.4e9 / (4 * it * 4)  # wave-butterflies per SIMD: 4 waves x it x 4
         res[name] = {"ms": ms, "cycles_per_wave_butterfly_at_2.4GHz": cyc, "Gbutterfly_per_s": 1024 * 256 * 4.0 * it / ms / 1e6}
