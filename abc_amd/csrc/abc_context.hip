@@ -158,6 +158,8 @@ static int build_context(abc_hip_ctx *c) {
     k.inv_special[j] = invmod(qsp % q, q);
     k.inv_special_s[j] = shoup(k.inv_special[j], q);
     k.special_mod_q[j] = qsp % q;
+    k.inv_special_c[j] = k.inv_special[j] > q / 2 ? -(double)(q - k.inv_special[j]) : (double)k.inv_special[j];
+    k.inv_special_cq[j] = k.inv_special_c[j] / (double)q;
   }
   for (int l = 1; l < L; l++)
     for (int j = 0; j < l; j++) {

@@ -250,6 +250,195 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_bfv(DevCtx 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp64 twins of the transform kernels above, taken when every key prime is below 2^50 (abc_ntt.hpp, "fp64 residue
+// arithmetic").  Same buffers, same u64 memory format, bit-identical results; only the arithmetic between the HBM
+// load and the HBM store differs.
+// ---------------------------------------------------------------------------------------------------------------
+// x*y mod q for two residues |x|, |y| <= q: |result| < q  (|x y / q| 2^-52 <= 1/4, plus the rounding 1/2)
+__device__ __forceinline__ double fp_mulmod(double x, double y, double q, double qinv) {
+  const double h = x * y;
+  const double l = __builtin_fma(x, y, -h);
+  const double c = __builtin_rint(h * qinv);
+  return __builtin_fma(-c, q, h) + l;
+}
+// |r| < q -> canonical u64
+__device__ __forceinline__ u64 fp_small_to_canon(double r, double q) {
+  const u32 neg = (u32)((int)(u32)((u64)__double_as_longlong(r) >> 32) >> 31);
+  const u64 qb = (u64)__double_as_longlong(q);
+  const u64 add = ((u64)((u32)(qb >> 32) & neg) << 32) | (u64)((u32)qb & neg);
+  r += __longlong_as_double((long long)add);
+  return (u64)__double_as_longlong(r + 4503599627370496.0) & 0x000fffffffffffffull;
+}
+
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_intt_fp(DevCtx c, const u64 *__restrict__ a,
+                                                                         const u64 *__restrict__ b, u64 *__restrict__ c01,
+                                                                         u64 *__restrict__ c2coef, u64 *__restrict__ c2ntt, int nl) {
+  __shared__ double lds[lds_words(LB)];
+  const int j = blockIdx.x % nl;
+  const size_t ct = blockIdx.x / nl;
+  const size_t N = (size_t)1 << LB, pw = (size_t)nl * N;
+  const Mod m = c.mods[j];
+  const FpTable t = fp_table(c, j);
+  const double q = m.qd, qinv = m.qinv;
+  const u64 *__restrict__ a0 = a + ct * 2 * pw + j * N, *__restrict__ a1 = a0 + pw;
+  const u64 *__restrict__ b0 = b + ct * 2 * pw + j * N, *__restrict__ b1 = b0 + pw;
+  u64 *__restrict__ o0 = c01 + ct * 2 * pw + j * N, *__restrict__ o1 = o0 + pw;
+  u64 *__restrict__ dcoef = c2coef + (ct * nl + j) * N, *__restrict__ dntt = c2ntt + (ct * nl + j) * N;
+  ntt_inv_block_a<LB, FpArith>(
+      lds,
+      [&](int, int i) {
+        const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
+        o0[i] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
+        o1[i] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
+        const double v = fp_mulmod(x1, y1, q, qinv);
+        dntt[i] = fp_small_to_canon(v, q);
+        return v;
+      },
+      [&](int, int i, double v) { dcoef[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, q), q, qinv); }, t, m, 0, 0);
+}
+
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_intt_fp(DevCtx c, const u64 *__restrict__ src, size_t src_stride,
+                                                                          u64 *__restrict__ dst, int nl) {
+  __shared__ double lds[lds_words(LB)];
+  const size_t N = (size_t)1 << LB;
+  const int j = blockIdx.x % nl;
+  const size_t ct = blockIdx.x / nl;
+  const Mod m = c.mods[j];
+  const FpTable t = fp_table(c, j);
+  const u64 *__restrict__ s = src + ct * src_stride + (size_t)j * N;
+  u64 *__restrict__ d = dst + (size_t)blockIdx.x * N;
+  ntt_inv_block_a<LB, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(s[i]); },
+      [&](int, int i, double v) { d[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv); }, t, m, 0, 0);
+}
+
+// K2a.  No reduction of the operand limb modulo the target prime is needed at all: a forward transform tolerates
+// inputs up to 2^50 for targets below 2^49 (growth (1 + 2^-5)^14), and the 49/50-bit targets, which re-centre at
+// every pass, accept the at most 2q such an operand amounts to.  Outputs are stored as non-negative lazy
+// representatives in [q/2, 3q/2] (the inner product reduces anyway).
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_decomp_ntt_fp(DevCtx c, const u64 *__restrict__ coef, size_t coef_stride,
+                                                                           u64 *__restrict__ dec, int nl, int skip_diagonal) {
+  __shared__ double lds[lds_words(LB)];
+  const int J = blockIdx.x % nl;
+  const int I = (blockIdx.x / nl) % (nl + 1);
+  const size_t ct = blockIdx.x / ((size_t)nl * (nl + 1));
+  if (skip_diagonal && J == I) return;
+  const size_t N = (size_t)1 << LB;
+  const int ki = (I == nl) ? c.K - 1 : I;
+  const Mod m = c.mods[ki];
+  const FpTable t = fp_table(c, ki);
+  const u64 *__restrict__ src = coef + ct * coef_stride + (size_t)J * N;
+  u64 *__restrict__ dst = dec + ((ct * (nl + 1) + I) * nl + J) * N;
+  ntt_fwd_block_a<LB, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(src[i]); }, [&](int, int i, double v) { dst[i] = fp_to_lazy(v, m.qd, m.qinv); }, t,
+      m, 0, 0);
+}
+
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_special_intt_fp(DevCtx c, const u64 *__restrict__ tsp,
+                                                                             u64 *__restrict__ tlast) {
+  __shared__ double lds[lds_words(LB)];
+  const size_t N = (size_t)1 << LB;
+  const Mod m = c.mods[c.K - 1];
+  const FpTable t = fp_table(c, c.K - 1);
+  const double half = (double)(m.q >> 1);
+  const u64 *__restrict__ src = tsp + (size_t)blockIdx.x * N;
+  u64 *__restrict__ dst = tlast + (size_t)blockIdx.x * N;
+  ntt_inv_block_a<LB, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(src[i]); },
+      [&](int, int i, double v) { dst[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd) + half, m.qd, m.qinv); }, t, m, 0,
+      0);
+}
+
+// K3, CKKS.  The special-prime polynomial (< q_sp <= 2^50) plus the rounding fix enters the transform unreduced
+// (see K2a); the subtraction, the scaling by q_sp^-1 and the addend stay in doubles until the single
+// canonicalisation of the store.
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_fp(DevCtx c, const u64 *__restrict__ ksacc,
+                                                                        const u64 *__restrict__ tlast, const u64 *__restrict__ addend,
+                                                                        size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl) {
+  __shared__ double lds[lds_words(LB)];
+  const int j = blockIdx.x % nl;
+  const size_t cc = blockIdx.x / nl;  // ct*2 + comp
+  const size_t ct = cc >> 1;
+  const int comp = (int)(cc & 1);
+  const size_t N = (size_t)1 << LB;
+  const Mod m = c.mods[j];
+  const FpTable t = fp_table(c, j);
+  const u64 half = c.mods[c.K - 1].q >> 1;
+  const u64 hm = reduce64(half, m);
+  const double fix = hm ? (double)(m.q - hm) : 0.0;
+  const double inv = c.cst->inv_special_c[j], inv_q = c.cst->inv_special_cq[j];
+  const u64 *__restrict__ src = tlast + cc * N;
+  const u64 *__restrict__ ks = ksacc + (cc * nl + j) * N;
+  u64 *__restrict__ o = out + (cc * nl + j) * N;
+  auto ld = [&](int, int i) { return fp_from_u64(src[i]) + fix; };
+  if (addend && (comp == 0 || add_c1)) {  // workgroup-uniform: two straight-line bodies, no per-element select
+    const u64 *__restrict__ cin = addend + ct * addend_stride + ((size_t)comp * nl + j) * N;
+    ntt_fwd_block_a<LB, FpArith>(
+        lds, ld,
+        [&](int, int i, double v) {
+          const double d = fp_from_u64(ks[i]) - v;
+          o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd) + fp_from_u64(cin[i]), m.qd, m.qinv);
+        },
+        t, m, 0, 0);
+  } else {
+    ntt_fwd_block_a<LB, FpArith>(
+        lds, ld,
+        [&](int, int i, double v) {
+          const double d = fp_from_u64(ks[i]) - v;
+          o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd), m.qd, m.qinv);
+        },
+        t, m, 0, 0);
+  }
+}
+
+// K3, BFV
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_bfv_fp(DevCtx c, const u64 *__restrict__ ksacc,
+                                                                            const u64 *__restrict__ tlast,
+                                                                            const u64 *__restrict__ addend, size_t addend_stride,
+                                                                            int add_c1, u64 *__restrict__ out, int nl) {
+  __shared__ double lds[lds_words(LB)];
+  const int j = blockIdx.x % nl;
+  const size_t cc = blockIdx.x / nl;
+  const size_t ct = cc >> 1;
+  const int comp = (int)(cc & 1);
+  const size_t N = (size_t)1 << LB;
+  const Mod m = c.mods[j];
+  const FpTable t = fp_table(c, j);
+  const u64 half = c.mods[c.K - 1].q >> 1;
+  const u64 hm = reduce64(half, m);
+  const double fix = hm ? (double)(m.q - hm) : 0.0;
+  const double inv = c.cst->inv_special_c[j], inv_q = c.cst->inv_special_cq[j];
+  const u64 *__restrict__ src = tlast + cc * N;
+  const u64 *__restrict__ ks = ksacc + (cc * nl + j) * N;
+  u64 *__restrict__ o = out + (cc * nl + j) * N;
+  auto ld = [&](int, int i) { return fp_from_u64(ks[i]); };
+  if (addend && (comp == 0 || add_c1)) {
+    const u64 *__restrict__ cin = addend + ct * addend_stride + ((size_t)comp * nl + j) * N;
+    ntt_inv_block_a<LB, FpArith>(
+        lds, ld,
+        [&](int, int i, double v) {
+          const double d = fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd) - (fp_from_u64(src[i]) + fix);
+          o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd) + fp_from_u64(cin[i]), m.qd, m.qinv);
+        },
+        t, m, 0, 0);
+  } else {
+    ntt_inv_block_a<LB, FpArith>(
+        lds, ld,
+        [&](int, int i, double v) {
+          const double d = fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd) - (fp_from_u64(src[i]) + fix);
+          o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd), m.qd, m.qinv);
+        },
+        t, m, 0, 0);
+  }
+}
+
 // scratch limbs per ciphertext: coef L, ntt L, dec L(L+1), ksacc 2L, tsp 2, tlast 2, c01 2L
 static inline size_t fused_scratch_limbs(int nl) { return (size_t)nl * (nl + 1) + 6 * (size_t)nl + 4; }
 
@@ -268,6 +457,11 @@ static inline FusedScratch carve(u64 *base, size_t chunk, int nl, size_t N) {
   return s;
 }
 
+static inline bool all_fp(const abc_hip_ctx *c) {  // fp64 transforms: every key prime below 2^50
+  bool fp = c->use_fp;
+  for (int j = 0; j < c->K; j++) fp = fp && fp_ok(c->h_mods[j].bits);
+  return fp;
+}
 static inline bool needs_guard(const abc_hip_ctx *c) {  // unguarded butterflies need (2 logN + 4) q < 2^64 for every key prime
   bool guard = false;
   for (int j = 0; j < c->K; j++) guard = guard || !unguarded_ok(c->h_mods[j].bits);
@@ -284,6 +478,21 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
   const bool ckks = (c->scheme == 2);
   const bool guard = needs_guard(c);
   const unsigned g2a = (unsigned)(cc * (nl + 1) * nl);
+  const unsigned g3 = (unsigned)(cc * 2 * nl);
+  if (all_fp(c)) {
+    hipLaunchKernelGGL(k_fused_ks_decomp_ntt_fp<LB>, dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
+    hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
+                       ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
+    hipLaunchKernelGGL(k_fused_ks_special_intt_fp<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, s.tsp, s.tlast);
+    if (ckks)
+      hipLaunchKernelGGL(k_fused_ks_moddown_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
+                         add_c1 ? 1 : 0, out, nl);
+    else
+      hipLaunchKernelGGL(k_fused_ks_moddown_bfv_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
+                         add_c1 ? 1 : 0, out, nl);
+    ABC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   bool lazy = !guard;  // 4 products of a (< 64q) operand with a key residue must stay below 2^(k+63): k <= 55
   for (int j = 0; j < c->K; j++) lazy = lazy && c->h_mods[j].bits <= 55;
   if (guard)
@@ -298,7 +507,6 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
   hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
                      ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
   hipLaunchKernelGGL(k_fused_ks_special_intt<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, s.tsp, s.tlast);
-  const unsigned g3 = (unsigned)(cc * 2 * nl);
   if (!ckks)
     hipLaunchKernelGGL(k_fused_ks_moddown_bfv<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
                        add_c1 ? 1 : 0, out, nl);
@@ -369,8 +577,12 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
     const int l = (p.lanes > 1) ? turn % p.lanes : 0;
     hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
     const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, N);
-    hipLaunchKernelGGL(k_fused_tensor_intt<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
-                       b + off * ctw, s.c01, s.coef, s.ntt, nl);
+    if (all_fp(c))
+      hipLaunchKernelGGL(k_fused_tensor_intt_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
+                         b + off * ctw, s.c01, s.coef, s.ntt, nl);
+    else
+      hipLaunchKernelGGL(k_fused_tensor_intt<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
+                         b + off * ctw, s.c01, s.coef, s.ntt, nl);
     if (keyswitch_stage<LB>(c, st, s, s.coef, (size_t)nl * N, s.ntt, (size_t)nl * N, c->d_relin, s.c01, ctw, true, out + off * ctw,
                             nl, cc))
       return 1;
@@ -415,8 +627,12 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     const u64 *coef = tg;
     size_t coef_stride = target_stride;
     if (ckks) {  // operand arrives in NTT form: coefficient form via one in-LDS inverse transform per limb
-      hipLaunchKernelGGL(k_fused_operand_intt<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride,
-                         s.coef, nl);
+      if (all_fp(c))
+        hipLaunchKernelGGL(k_fused_operand_intt_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
+                           target_stride, s.coef, nl);
+      else
+        hipLaunchKernelGGL(k_fused_operand_intt<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride,
+                           s.coef, nl);
       coef = s.coef;
       coef_stride = (size_t)nl * N;
     }
