@@ -74,11 +74,20 @@ __device__ __forceinline__ NttTable ntt_table(const DevCtx &c, int mid) {
   return t;
 }
 
+// modulus constants through the constant address space (scalar loads wherever the id is wave-uniform; see FpTable)
+__device__ __forceinline__ Mod mod_at(const DevCtx &c, int id) {
+  const ABC_CONST_AS Mod *p = (const ABC_CONST_AS Mod *)(c.mods + id);
+  Mod m;
+  m.q = p->q; m.mu = p->mu; m.two_q = p->two_q; m.shift = p->shift; m.bits = p->bits;
+  m.inv_n = p->inv_n; m.inv_n_s = p->inv_n_s; m.qd = p->qd; m.qinv = p->qinv;
+  m.inv_n_c = p->inv_n_c; m.inv_n_cq = p->inv_n_cq;
+  return m;
+}
 __device__ __forceinline__ FpTable fp_table(const DevCtx &c, int mid) {
   const double *b = c.ftw + (size_t)mid * 4 * c.n;
   FpTable t;
-  t.tw = reinterpret_cast<const f64x2 *>(b);
-  t.itw = reinterpret_cast<const f64x2 *>(b + 2 * (size_t)c.n);
+  t.tw = (const ABC_CONST_AS f64x2 *)(b);
+  t.itw = (const ABC_CONST_AS f64x2 *)(b + 2 * (size_t)c.n);
   return t;
 }
 

@@ -279,7 +279,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_intt_fp(DevCtx 
   const int j = blockIdx.x % nl;
   const size_t ct = blockIdx.x / nl;
   const size_t N = (size_t)1 << LB, pw = (size_t)nl * N;
-  const Mod m = c.mods[j];
+  const Mod m = mod_at(c, j);
   const FpTable t = fp_table(c, j);
   const double q = m.qd, qinv = m.qinv;
   const u64 *__restrict__ a0 = a + ct * 2 * pw + j * N, *__restrict__ a1 = a0 + pw;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_intt_fp(DevCtx
   const size_t N = (size_t)1 << LB;
   const int j = blockIdx.x % nl;
   const size_t ct = blockIdx.x / nl;
-  const Mod m = c.mods[j];
+  const Mod m = mod_at(c, j);
   const FpTable t = fp_table(c, j);
   const u64 *__restrict__ s = src + ct * src_stride + (size_t)j * N;
   u64 *__restrict__ d = dst + (size_t)blockIdx.x * N;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_decomp_ntt_fp(DevCt
   if (skip_diagonal && J == I) return;
   const size_t N = (size_t)1 << LB;
   const int ki = (I == nl) ? c.K - 1 : I;
-  const Mod m = c.mods[ki];
+  const Mod m = mod_at(c, ki);
   const FpTable t = fp_table(c, ki);
   const u64 *__restrict__ src = coef + ct * coef_stride + (size_t)J * N;
   u64 *__restrict__ dst = dec + ((ct * (nl + 1) + I) * nl + J) * N;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_special_intt_fp(Dev
                                                                              u64 *__restrict__ tlast) {
   __shared__ double lds[lds_words(LB)];
   const size_t N = (size_t)1 << LB;
-  const Mod m = c.mods[c.K - 1];
+  const Mod m = mod_at(c, c.K - 1);
   const FpTable t = fp_table(c, c.K - 1);
   const double half = (double)(m.q >> 1);
   const u64 *__restrict__ src = tsp + (size_t)blockIdx.x * N;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_fp(DevCtx c
   const size_t ct = cc >> 1;
   const int comp = (int)(cc & 1);
   const size_t N = (size_t)1 << LB;
-  const Mod m = c.mods[j];
+  const Mod m = mod_at(c, j);
   const FpTable t = fp_table(c, j);
   const u64 half = c.mods[c.K - 1].q >> 1;
   const u64 hm = reduce64(half, m);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_bfv_fp(DevC
   const size_t ct = cc >> 1;
   const int comp = (int)(cc & 1);
   const size_t N = (size_t)1 << LB;
-  const Mod m = c.mods[j];
+  const Mod m = mod_at(c, j);
   const FpTable t = fp_table(c, j);
   const u64 half = c.mods[c.K - 1].q >> 1;
   const u64 hm = reduce64(half, m);
@@ -437,6 +437,170 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_bfv_fp(DevC
         },
         t, m, 0, 0);
   }
+}
+
+// K1 + K2a in one workgroup (CKKS multiply): the coefficients of c2_j leave the inverse transform in exactly the
+// register layout the forward transform's first pass loads (PassIdx<LB,0,R0> both ways), so they stay in 16
+// registers per lane and feed the nl forward transforms modulo the other key primes back to back -- the
+// coefficient form of c2 never touches HBM (saves 4 + 16 limb transfers per ciphertext and one launch).
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_decomp_fp(DevCtx c, const u64 *__restrict__ a,
+                                                                           const u64 *__restrict__ b, u64 *__restrict__ c01,
+                                                                           u64 *__restrict__ c2ntt, u64 *__restrict__ dec, int nl) {
+  __shared__ double lds[lds_words(LB)];
+  const int j = blockIdx.x % nl;
+  const size_t ct = blockIdx.x / nl;
+  const size_t N = (size_t)1 << LB, pw = (size_t)nl * N;
+  double src[16];
+  {
+    const Mod m = mod_at(c, j);
+    const FpTable t = fp_table(c, j);
+    const double q = m.qd, qinv = m.qinv;
+    const u64 *__restrict__ a0 = a + ct * 2 * pw + j * N, *__restrict__ a1 = a0 + pw;
+    const u64 *__restrict__ b0 = b + ct * 2 * pw + j * N, *__restrict__ b1 = b0 + pw;
+    u64 *__restrict__ o0 = c01 + ct * 2 * pw + j * N, *__restrict__ o1 = o0 + pw;
+    u64 *__restrict__ dntt = c2ntt + (ct * nl + j) * N;
+    ntt_inv_block_a<LB, FpArith>(
+        lds,
+        [&](int, int i) {
+          const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
+          o0[i] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
+          o1[i] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
+          const double v = fp_mulmod(x1, y1, q, qinv);
+          dntt[i] = fp_small_to_canon(v, q);
+          return v;
+        },
+        // canonical [0, q_j) as a double: the value SEAL's decomposition reduces modulo the other primes
+        [&](int r, int, double v) {
+          double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, q), q, qinv);
+          src[r] = w < 0.0 ? w + q : w;
+        },
+        t, m, 0, 0);
+  }
+  for (int I = 0; I <= nl; I++) {
+    if (I == j) continue;
+    const int ki = (I == nl) ? c.K - 1 : I;
+    const Mod m = mod_at(c, ki);
+    const FpTable t = fp_table(c, ki);
+    u64 *__restrict__ dst = dec + ((ct * (nl + 1) + I) * nl + j) * N;
+    block_sync_lds();  // the previous transform's last pass has read its LDS words
+    ntt_fwd_block_a<LB, FpArith>(
+        lds, [&](int r, int) { return src[r]; }, [&](int, int i, double v) { dst[i] = fp_to_lazy(v, m.qd, m.qinv); }, t, m, 0, 0);
+  }
+}
+
+// ---- split transforms (N = 2^14) ------------------------------------------------------------------------------------
+// A 2^14-point forward transform is a radix-16 pass over stride-1024 elements (stages 0..3, no LDS: the sixteen
+// operands of a lane are exactly what the inverse transform's last pass leaves in its registers) followed by
+// sixteen independent 1024-point transforms (stages 4..13) that one wavefront each completes in 8.5 KiB of LDS.
+// K1s does the LDS-resident part (tensor product, inverse transform of c2_j) and the register pass of the nl
+// forward transforms, and stores the half-done limbs as raw doubles; K2s finishes them block by block and
+// multiplies into the key on the fly.  K2s workgroups are single wavefronts (no 128-VGPR ceiling, so both
+// accumulators fit in registers, and a dozen of them share a CU, so their HBM phases overlap each other's
+// arithmetic -- which a 1024-thread, 139 KiB workgroup cannot do with itself).
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_pass0_fp(DevCtx c, const u64 *__restrict__ a,
+                                                                          const u64 *__restrict__ b, u64 *__restrict__ c01,
+                                                                          u64 *__restrict__ c2ntt, double *__restrict__ part, int nl) {
+  static_assert(LB == 14, "split transforms are laid out for N = 2^14");
+  __shared__ double lds[lds_words(LB)];
+  const int j = blockIdx.x % nl;
+  const size_t ct = blockIdx.x / nl;
+  const size_t N = (size_t)1 << LB, pw = (size_t)nl * N;
+  const int tid = threadIdx.x;
+  double src[16];
+  {
+    const Mod m = mod_at(c, j);
+    const FpTable t = fp_table(c, j);
+    const double q = m.qd, qinv = m.qinv;
+    const u64 *__restrict__ a0 = a + ct * 2 * pw + j * N, *__restrict__ a1 = a0 + pw;
+    const u64 *__restrict__ b0 = b + ct * 2 * pw + j * N, *__restrict__ b1 = b0 + pw;
+    u64 *__restrict__ o0 = c01 + ct * 2 * pw + j * N, *__restrict__ o1 = o0 + pw;
+    u64 *__restrict__ dntt = c2ntt + (ct * nl + j) * N;
+    ntt_inv_block_a<LB, FpArith>(
+        lds,
+        [&](int, int i) {
+          const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
+          o0[i] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
+          o1[i] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
+          const double v = fp_mulmod(x1, y1, q, qinv);
+          dntt[i] = fp_small_to_canon(v, q);
+          return v;
+        },
+        [&](int r, int, double v) {
+          double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, q), q, qinv);
+          src[r] = w < 0.0 ? w + q : w;
+        },
+        t, m, 0, 0);
+  }
+  const int hi0[1] = {0};
+  for (int I = 0; I <= nl; I++) {
+    if (I == j) continue;
+    const int ki = (I == nl) ? c.K - 1 : I;
+    const Mod m = mod_at(c, ki);
+    const FpTable t = fp_table(c, ki);
+    const FpK kk = FpArith::consts(m);
+    double y[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) y[k] = src[k];
+    fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
+    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * N;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(k << 10) + tid] = y[k];
+  }
+}
+
+// K2s: workgroup (ct, I, block): x_J = stages 4..13 of the half-done limb (ct, I, J) on this 1024-point block (for
+// J = I, CKKS: the operand's own NTT form), acc_c += x_J * key[J][c][I]; canonical sums to ksacc / tsp.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_fused_tailmac_fp(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ ntt,
+                                                         size_t ntt_stride, const u64 *__restrict__ key, u64 *__restrict__ ksacc,
+                                                         u64 *__restrict__ tsp, int nl) {
+  __shared__ double lds[lds_words(10)];
+  const int blk = blockIdx.x & 15;
+  const int I = (blockIdx.x >> 4) % (nl + 1);
+  const size_t ct = (blockIdx.x >> 4) / (nl + 1);
+  const size_t N = (size_t)c.n;
+  const int ki = (I == nl) ? c.K - 1 : I;
+  const Mod m = mod_at(c, ki);
+  const FpTable t = fp_table(c, ki);
+  const double q = m.qd, qinv = m.qinv;
+  const int tid = threadIdx.x;
+  double acc0[16], acc1[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc0[r] = acc1[r] = 0.0;
+  for (int J = 0; J < nl; J++) {
+    const u64 *__restrict__ k0 = key + (((size_t)J * 2 + 0) * c.K + ki) * N + ((size_t)blk << 10);
+    const u64 *__restrict__ k1 = key + (((size_t)J * 2 + 1) * c.K + ki) * N + ((size_t)blk << 10);
+    auto accum = [&](int r, int i, double v) {
+      acc0[r] += fp_mulmod(v, fp_from_u64(k0[i]), q, qinv);
+      acc1[r] += fp_mulmod(v, fp_from_u64(k1[i]), q, qinv);
+    };
+    if (ntt && J == I) {
+      const u64 *__restrict__ xs = ntt + ct * ntt_stride + (size_t)J * N + ((size_t)blk << 10);
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i = 4 * (tid + 64 * g) + k;
+          accum(4 * g + k, i, fp_from_u64(xs[i]));
+        }
+    } else {
+      const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
+      wave_sync();  // single wavefront: the previous transform's LDS reads are ordered before these writes
+      ntt_fwd_block_a<10, FpArith>(
+          lds, [&](int, int i) { return fp_centre(src[i], q, qinv); }, accum, t, m, 4, blk);
+    }
+  }
+  u64 *__restrict__ o0 = (I == nl) ? tsp + (ct * 2 + 0) * N : ksacc + ((ct * 2 + 0) * nl + I) * N;
+  u64 *__restrict__ o1 = (I == nl) ? tsp + (ct * 2 + 1) * N : ksacc + ((ct * 2 + 1) * nl + I) * N;
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t i = ((size_t)blk << 10) + 4 * (tid + 64 * g) + k;
+      o0[i] = fp_to_canon(acc0[4 * g + k], q, qinv);
+      o1[i] = fp_to_canon(acc1[4 * g + k], q, qinv);
+    }
 }
 
 // scratch limbs per ciphertext: coef L, ntt L, dec L(L+1), ksacc 2L, tsp 2, tlast 2, c01 2L
@@ -472,7 +636,7 @@ static inline bool needs_guard(const abc_hip_ctx *c) {  // unguarded butterflies
 template <int LB>
 static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s, const u64 *coef, size_t coef_stride, const u64 *ntt,
                            size_t ntt_stride, const u64 *key, const u64 *addend, size_t addend_stride, bool add_c1, u64 *out, int nl,
-                           size_t cc) {
+                           size_t cc, int dec_ready = 0 /* 1: dec holds finished limbs, 2: half-done limbs (split) */) {
   const size_t N = (size_t)1 << LB;
   const dim3 block((1 << LB) / 16);
   const bool ckks = (c->scheme == 2);
@@ -480,9 +644,14 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
   const unsigned g2a = (unsigned)(cc * (nl + 1) * nl);
   const unsigned g3 = (unsigned)(cc * 2 * nl);
   if (all_fp(c)) {
-    hipLaunchKernelGGL(k_fused_ks_decomp_ntt_fp<LB>, dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
-    hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
-                       ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
+    if (!dec_ready)
+      hipLaunchKernelGGL(k_fused_ks_decomp_ntt_fp<LB>, dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
+    if (dec_ready == 2)
+      hipLaunchKernelGGL(k_fused_tailmac_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64), 0, st, c->dc, (const double *)s.dec,
+                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl);
+    else
+      hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
+                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
     hipLaunchKernelGGL(k_fused_ks_special_intt_fp<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, s.tsp, s.tlast);
     if (ckks)
       hipLaunchKernelGGL(k_fused_ks_moddown_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
@@ -577,14 +746,26 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
     const int l = (p.lanes > 1) ? turn % p.lanes : 0;
     hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
     const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, N);
-    if (all_fp(c))
+    const bool fuse_decomp = all_fp(c) && !std::getenv("ABC_HIP_NO_TENSOR_DECOMP");
+    bool split = false;
+    if constexpr (LB == 14) split = fuse_decomp && !std::getenv("ABC_HIP_NO_SPLIT");
+    if constexpr (LB == 14) {
+      if (split)
+        hipLaunchKernelGGL(k_fused_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
+                           b + off * ctw, s.c01, s.ntt, (double *)s.dec, nl);
+    }
+    if (split) {
+    } else if (fuse_decomp)
+      hipLaunchKernelGGL(k_fused_tensor_decomp_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
+                         b + off * ctw, s.c01, s.ntt, s.dec, nl);
+    else if (all_fp(c))
       hipLaunchKernelGGL(k_fused_tensor_intt_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
                          b + off * ctw, s.c01, s.coef, s.ntt, nl);
     else
       hipLaunchKernelGGL(k_fused_tensor_intt<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
                          b + off * ctw, s.c01, s.coef, s.ntt, nl);
     if (keyswitch_stage<LB>(c, st, s, s.coef, (size_t)nl * N, s.ntt, (size_t)nl * N, c->d_relin, s.c01, ctw, true, out + off * ctw,
-                            nl, cc))
+                            nl, cc, split ? 2 : (fuse_decomp ? 1 : 0)))
       return 1;
   }
   return join_lanes(c, p.lanes);

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void k_mb_fma64(const Mod *mods, u64 *sink, in
 // Each lane performs 4*iters operations; grid = 256 CUs x 8 workgroups x 256 lanes.
 int microbench_instr(abc_hip_ctx *c, int which, int iters, double *ms);
 int microbench_bfly(abc_hip_ctx *c, int which, int iters, double *ms);
+int microbench_ntt(abc_hip_ctx *c, int which, int iters, double *ms);
 int microbench(abc_hip_ctx *c, int which, int iters, double *ms) {
+  if (which >= 300) return microbench_ntt(c, which - 300, iters, ms);
   if (which >= 200) return microbench_bfly(c, which - 200, iters, ms);
   if (which >= 100) return microbench_instr(c, which - 100, iters, ms);
   const int blocks = 256 * 8, threads = 256;
@@ -285,6 +287,163 @@ int microbench_bfly(abc_hip_ctx *c, int which, int iters, double *ms) {
     float t = 0;
     ABC_HIP_CHECK(hipEventElapsedTime(&t, c->ev0, c->ev1));
     if (t < best) best = t;
+  }
+  *ms = best;
+  return 0;
+}
+}  // namespace abc
+
+// ---- where does a transform's time go: fp64 2^14-point forward transform with the HBM load and / or store cut out ----
+namespace abc {
+template <int MODE>  // bit 0: no global loads (synthetic input), bit 1: no global stores (one word per lane instead of 16)
+__global__ __launch_bounds__(1024) void k_mb_ntt(DevCtx c, u64 *data, int mid) {
+  __shared__ double lds[lds_words(14)];
+  const Mod m = c.mods[mid];
+  const FpTable t = fp_table(c, mid);
+  u64 *base = data + (size_t)blockIdx.x * c.n;
+  double sink = 0.0;
+  ntt_fwd_block_a<14, FpArith>(
+      lds, [&](int, int i) { return (MODE & 1) ? (double)(i ^ (int)blockIdx.x) : fp_from_u64(base[i]); },
+      [&](int, int i, double v) {
+        if (MODE & 2)
+          sink += v;
+        else
+          base[i] = fp_to_canon(v, m.qd, m.qinv);
+      },
+      t, m, 0, 0);
+  if ((MODE & 2) && sink == 12345.678) base[threadIdx.x] = 1;
+}
+
+// staggered start: the first workgroup on each CU waits a pseudo-random fraction of one transform period, so the CUs
+// stop marching through their load / compute / store phases in lockstep
+__global__ __launch_bounds__(1024) void k_mb_ntt_stagger(DevCtx c, u64 *data, int mid, int ticks) {
+  __shared__ double lds[lds_words(14)];
+  if (blockIdx.x < 256) {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long d = (unsigned long long)((blockIdx.x * 37u) & 255u) * (unsigned)ticks / 256u;
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
+  const Mod m = mod_at(c, mid);
+  const FpTable t = fp_table(c, mid);
+  u64 *base = data + (size_t)blockIdx.x * c.n;
+  ntt_fwd_block_a<14, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(base[i]); }, [&](int, int i, double v) { base[i] = fp_to_canon(v, m.qd, m.qinv); },
+      t, m, 0, 0);
+}
+
+// persistent form: 256 x PER workgroups walk the transforms; the next transform's 16 words per lane are fetched into
+// registers before the current one is computed
+template <bool PREFETCH>
+__global__ __launch_bounds__(1024) void k_mb_ntt_persistent(DevCtx c, u64 *data, int mid, int total) {
+  __shared__ double lds[lds_words(14)];
+  const Mod m = c.mods[mid];
+  const FpTable t = fp_table(c, mid);
+  const int tid = threadIdx.x;
+  u64 raw[16];
+  int w = blockIdx.x;
+  if (PREFETCH && w < total) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) raw[k] = data[(size_t)w * c.n + (k << 10) + tid];
+  }
+  for (; w < total; w += gridDim.x) {
+    u64 *base = data + (size_t)w * c.n;
+    double x[16];
+    if (PREFETCH) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) x[k] = fp_from_u64(raw[k]);
+      const int wn = w + gridDim.x;
+      if (wn < total) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) raw[k] = data[(size_t)wn * c.n + (k << 10) + tid];
+      }
+    }
+    block_sync_lds();
+    ntt_fwd_block_a<14, FpArith>(
+        lds, [&](int r, int i) { return PREFETCH ? x[r] : fp_from_u64(base[i]); },
+        [&](int, int i, double v) { base[i] = fp_to_canon(v, m.qd, m.qinv); }, t, m, 0, 0);
+  }
+}
+
+// split form: two 512-thread workgroups per transform, each folds stage 0 into its load and runs the remaining 13
+// stages on its half (68 KiB of LDS, so two workgroups share a CU and their HBM phases overlap the other's compute)
+__global__ __launch_bounds__(512) void k_mb_ntt_split(DevCtx c, const u64 *src, u64 *dst, int mid, int pair_stride) {
+  __shared__ double lds[lds_words(13)];
+  const Mod m = c.mods[mid];
+  const FpTable t = fp_table(c, mid);
+  // workgroups w and w + pair_stride work on the two halves of one transform
+  const int h = (blockIdx.x / pair_stride) & 1;
+  const size_t limb = (size_t)(blockIdx.x / (2 * pair_stride)) * pair_stride + (blockIdx.x % pair_stride);
+  const u64 *base = src + limb * c.n;
+  u64 *out = dst + limb * c.n + ((size_t)h << 13);
+  const f64x2 w0 = tw_load(t.tw + 1);
+  const double q = m.qd;
+  if (h == 0)
+    ntt_fwd_block_a<13, FpArith>(
+        lds, [&](int, int i) { return fp_from_u64(base[i]) + fp_mul_lazy(fp_from_u64(base[i + 8192]), w0.x, w0.y, q); },
+        [&](int, int i, double v) { out[i] = fp_to_canon(v, m.qd, m.qinv); }, t, m, 1, 0);
+  else
+    ntt_fwd_block_a<13, FpArith>(
+        lds, [&](int, int i) { return fp_from_u64(base[i]) - fp_mul_lazy(fp_from_u64(base[i + 8192]), w0.x, w0.y, q); },
+        [&](int, int i, double v) { out[i] = fp_to_canon(v, m.qd, m.qinv); }, t, m, 1, 1);
+}
+
+// memory-only references: the transform's HBM access pattern with no arithmetic, and a plain streaming copy
+__global__ __launch_bounds__(1024) void k_mb_copy_pattern(DevCtx c, const u64 *src, u64 *dst) {
+  const u64 *base = src + (size_t)blockIdx.x * c.n;
+  u64 *out = dst + (size_t)blockIdx.x * c.n;
+  const int tid = threadIdx.x;
+  u64 x[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) x[k] = base[(k << 10) + tid];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    u64x2 *o = reinterpret_cast<u64x2 *>(out + 4 * (tid + 1024 * g));
+    o[0] = u64x2{x[4 * g] + 1, x[4 * g + 1] + 1};
+    o[1] = u64x2{x[4 * g + 2] + 1, x[4 * g + 3] + 1};
+  }
+}
+__global__ __launch_bounds__(256) void k_mb_copy_stream(const u64x2 *src, u64x2 *dst, size_t n2) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    u64x2 v = src[i];
+    v.x += 1;
+    dst[i] = v;
+  }
+}
+
+int microbench_ntt(abc_hip_ctx *c, int which, int iters, double *ms) {
+  if (c->logn != 14) { set_error("microbench: transform probes need N = 2^14"); return 1; }
+  const int limbs = iters;  // number of transforms in the launch
+  if (ensure_workspace(c, (size_t)2 * limbs * c->n * 8)) return 1;
+  u64 *d = (u64 *)c->ws, *d2 = d + (size_t)limbs * c->n;
+  ABC_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)limbs * c->n * 8, c->stream));
+  float best = 1e30f;
+  const int mid = 1;
+  for (int rep = 0; rep < 4; rep++) {
+    ABC_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    switch (which) {
+      case 0: hipLaunchKernelGGL(k_mb_ntt<0>, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid); break;
+      case 1: hipLaunchKernelGGL(k_mb_ntt<1>, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid); break;
+      case 2: hipLaunchKernelGGL(k_mb_ntt<2>, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid); break;
+      case 3: hipLaunchKernelGGL(k_mb_ntt<3>, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid); break;
+      case 4: hipLaunchKernelGGL(k_mb_ntt_persistent<false>, dim3(256), dim3(1024), 0, c->stream, c->dc, d, mid, limbs); break;
+      case 6: hipLaunchKernelGGL(k_mb_ntt_split, dim3(2 * limbs), dim3(512), 0, c->stream, c->dc, d, d2, mid, 1); break;
+      case 7: hipLaunchKernelGGL(k_mb_ntt_split, dim3(2 * limbs), dim3(512), 0, c->stream, c->dc, d, d2, mid, 8); break;
+      case 8: hipLaunchKernelGGL(k_mb_copy_pattern, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, d2); break;
+      case 9: hipLaunchKernelGGL(k_mb_copy_stream, dim3(256 * 16), dim3(256), 0, c->stream, (const u64x2 *)d, (u64x2 *)d2,
+                                 (size_t)limbs * c->n / 2); break;
+      case 10: hipLaunchKernelGGL(k_mb_ntt_stagger, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid, 600); break;
+      case 11: hipLaunchKernelGGL(k_mb_ntt_stagger, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid, 1200); break;
+      case 12: hipLaunchKernelGGL(k_mb_ntt_stagger, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid, 1700); break;
+      case 5: hipLaunchKernelGGL(k_mb_ntt_persistent<true>, dim3(256), dim3(1024), 0, c->stream, c->dc, d, mid, limbs); break;
+      default: set_error("microbench: unknown transform probe"); return 1;
+    }
+    ABC_HIP_CHECK(hipGetLastError());
+    ABC_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    ABC_HIP_CHECK(hipEventSynchronize(c->ev1));
+    float t = 0;
+    ABC_HIP_CHECK(hipEventElapsedTime(&t, c->ev0, c->ev1));
+    if (rep && t < best) best = t;
   }
   *ms = best;
   return 0;

@@ -35,9 +35,22 @@ struct NttTable {
 struct alignas(16) f64x2 {
   double x, y;
 };
+// The tables are read through the constant address space: they never change while a kernel runs, and saying so lets
+// the compiler keep wave-uniform twiddles on the scalar unit (s_load, lgkmcnt) even in kernels that store to HBM
+// between two transforms.  On gfx950 loads and stores share one in-order vmcnt, so a twiddle fetched with a vector
+// load would make the wave wait for every store issued before it -- which is exactly what must not happen if the
+// stores of one transform are to drain under the first passes of the next.
+#define ABC_CONST_AS __attribute__((address_space(4)))
 struct FpTable {
-  const f64x2 *tw, *itw;
+  const ABC_CONST_AS f64x2 *tw, *itw;
 };
+__device__ __forceinline__ f64x2 tw_load(const ABC_CONST_AS f64x2 *p) {
+  f64x2 r;
+  r.x = p->x;
+  r.y = p->y;
+  return r;
+}
+__device__ __forceinline__ u64x2 tw_load(const u64x2 *p) { return *p; }
 
 // ---- fp64 residue arithmetic (primes < 2^50) ------------------------------------------------------------
 // Residues are integer-valued doubles, signed and lazily reduced.  Every operation below is exact as long as
@@ -173,7 +186,7 @@ __device__ __forceinline__ void fwd_pass(typename A::E (&x)[16], const int (&hi)
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
         int idx = base + (k >> (R - u));
-        A::fwd(x[g * (1 << R) + k], x[g * (1 << R) + (k | half)], t.tw[idx], kk);
+        A::fwd(x[g * (1 << R) + k], x[g * (1 << R) + (k | half)], tw_load(t.tw + idx), kk);
       }
     }
   }
@@ -194,7 +207,7 @@ __device__ __forceinline__ void inv_pass(typename A::E (&x)[16], const int (&hi)
       for (int k = 0; k < (1 << R); k++) {
         if (k & half) continue;
         int idx = base + (k >> (R - u));
-        A::inv(x[g * (1 << R) + k], x[g * (1 << R) + (k | half)], t.itw[idx], kk);
+        A::inv(x[g * (1 << R) + k], x[g * (1 << R) + (k | half)], tw_load(t.itw + idx), kk);
       }
     }
   }

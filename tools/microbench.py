@@ -39,6 +39,16 @@ def main():
         cyc = ms * 1e-3 * 2.4e9 / (4 * it * 4)  # wave-butterflies per SIMD: 4 waves x it x 4
         res[name] = {"ms": ms, "cycles_per_wave_butterfly_at_2.4GHz": cyc, "Gbutterfly_per_s": 1024 * 256 * 4.0 * it / ms / 1e6}
         print("%-20s %8.3f ms  %6.1f cycles per wave-butterfly (if 2.4 GHz)  %8.0f Gbfly/s" % (name, ms, cyc, res[name]["Gbutterfly_per_s"]), flush=True)
+    # fp64 forward transform, 4096 per launch, with the HBM load / store phases cut out
+    for which, name in ((300, "ntt_fp_full"), (301, "ntt_fp_no_load"), (302, "ntt_fp_no_store"), (303, "ntt_fp_no_load_no_store"),
+                        (304, "ntt_fp_persistent"), (305, "ntt_fp_persistent_prefetch"),
+                        (306, "ntt_fp_split_adjacent"), (307, "ntt_fp_split_same_xcd"),
+                        (308, "copy_transform_pattern"), (309, "copy_streaming"),
+                        (310, "ntt_fp_stagger_6us"), (311, "ntt_fp_stagger_12us"), (312, "ntt_fp_stagger_17us")):
+        ms = g.microbench(which, 4096)
+        res[name] = {"ms": ms, "us_per_transform_per_cu": ms * 1e3 / 4096 * 256}
+        print("%-26s %8.3f ms  %6.2f us per transform per CU  (%.0f GB/s if 256 KiB per transform)" %
+              (name, ms, ms * 1e3 / 4096 * 256, 4096 * 262144 / ms / 1e6), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/microbench.json", "w") as f:
         json.dump(res, f, indent=1)
