@@ -550,6 +550,51 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_pass0_fp(DevCtx
   }
 }
 
+// K1s for a general key switch.  CKKS (the operand arrives in NTT form): inverse transform of limb j in LDS, then the
+// register pass modulo every other key prime.  BFV (coefficient form): no LDS at all, the register pass modulo every key
+// prime including q_j itself.
+template <int LB, bool CKKS>
+__global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCtx c, const u64 *__restrict__ src, size_t src_stride,
+                                                                           double *__restrict__ part, int nl) {
+  static_assert(LB == 14, "split transforms are laid out for N = 2^14");
+  __shared__ double lds[CKKS ? lds_words(LB) : 1];
+  const size_t N = (size_t)1 << LB;
+  const int j = blockIdx.x % nl;
+  const size_t ct = blockIdx.x / nl;
+  const int tid = threadIdx.x;
+  const u64 *__restrict__ sp = src + ct * src_stride + (size_t)j * N;
+  double x[16];
+  if constexpr (CKKS) {
+    const Mod m = mod_at(c, j);
+    const FpTable t = fp_table(c, j);
+    ntt_inv_block_a<LB, FpArith>(
+        lds, [&](int, int i) { return fp_from_u64(sp[i]); },
+        [&](int r, int, double v) {
+          double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
+          x[r] = w < 0.0 ? w + m.qd : w;
+        },
+        t, m, 0, 0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = fp_from_u64(sp[(k << 10) + tid]);
+  }
+  const int hi0[1] = {0};
+  for (int I = 0; I <= nl; I++) {
+    if (CKKS && I == j) continue;
+    const int ki = (I == nl) ? c.K - 1 : I;
+    const Mod m = mod_at(c, ki);
+    const FpTable t = fp_table(c, ki);
+    const FpK kk = FpArith::consts(m);
+    double y[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) y[k] = x[k];
+    fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
+    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * N;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(k << 10) + tid] = y[k];
+  }
+}
+
 // K2s: workgroup (ct, I, block): x_J = stages 4..13 of the half-done limb (ct, I, J) on this 1024-point block (for
 // J = I, CKKS: the operand's own NTT form), acc_c += x_J * key[J][c][I]; canonical sums to ksacc / tsp.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_fused_tailmac_fp(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ ntt,
@@ -603,6 +648,70 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
     }
 }
 
+// K2s, cooperative form: one workgroup of nl wavefronts per (ct, I, block); wavefront J finishes limb J's block (or
+// takes the diagonal operand), multiplies by its two key slices and adds the products into two LDS accumulators
+// (ds_add_f64: sums of integer-valued doubles below 2^53 are exact in any order).  The nl operand loads of an item are
+// in flight together and no wavefront carries accumulators, so it runs at four wavefronts per SIMD.
+__global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const double *__restrict__ part,
+                                                                const u64 *__restrict__ ntt, size_t ntt_stride,
+                                                                const u64 *__restrict__ key, u64 *__restrict__ ksacc,
+                                                                u64 *__restrict__ tsp, int nl) {
+  extern __shared__ double dyn[];
+  double *acc = dyn;  // [2][4][256]: component, k, p  (element 4p + k of the block): lanes walk p, conflict-free
+  const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  double *lds = dyn + 2048 + J * lds_words(10);
+  const int blk = blockIdx.x & 15;
+  const int I = (blockIdx.x >> 4) % (nl + 1);
+  const size_t ct = (blockIdx.x >> 4) / (nl + 1);
+  const size_t N = (size_t)c.n;
+  const int ki = (I == nl) ? c.K - 1 : I;
+  const Mod m = mod_at(c, ki);
+  const FpTable t = fp_table(c, ki);
+  const double q = m.qd, qinv = m.qinv;
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) acc[i] = 0.0;
+  __syncthreads();
+  {
+    const u64 *__restrict__ k0 = key + (((size_t)J * 2 + 0) * c.K + ki) * N + ((size_t)blk << 10);
+    const u64 *__restrict__ k1 = key + (((size_t)J * 2 + 1) * c.K + ki) * N + ((size_t)blk << 10);
+    auto accum = [&](int, int i, double v) {
+      const int slot = ((i & 3) << 8) + (i >> 2);
+      const double p0 = fp_mulmod(v, fp_from_u64(k0[i]), q, qinv);
+      const double p1 = fp_mulmod(v, fp_from_u64(k1[i]), q, qinv);
+      __hip_atomic_fetch_add(acc + slot, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(acc + 1024 + slot, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (ntt && J == I) {
+      const u64 *__restrict__ xs = ntt + ct * ntt_stride + (size_t)J * N + ((size_t)blk << 10);
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int i = 4 * (lane + 64 * g) + k;
+          accum(4 * g + k, i, fp_from_u64(xs[i]));
+        }
+    } else {
+      const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
+      ntt_fwd_block_a<10, FpArith>(
+          lds, [&](int, int i) { return fp_centre(src[i], q, qinv); }, accum, t, m, 4, blk, lane);
+    }
+  }
+  __syncthreads();
+  u64 *__restrict__ o0 = ((I == nl) ? tsp + (ct * 2 + 0) * N : ksacc + ((ct * 2 + 0) * nl + I) * N) + ((size_t)blk << 10);
+  u64 *__restrict__ o1 = ((I == nl) ? tsp + (ct * 2 + 1) * N : ksacc + ((ct * 2 + 1) * nl + I) * N) + ((size_t)blk << 10);
+  for (int p = threadIdx.x; p < 256; p += blockDim.x) {
+    u64x2 r;
+    r.x = fp_to_canon(acc[p], q, qinv); r.y = fp_to_canon(acc[256 + p], q, qinv);
+    *reinterpret_cast<u64x2 *>(o0 + 4 * p) = r;
+    r.x = fp_to_canon(acc[512 + p], q, qinv); r.y = fp_to_canon(acc[768 + p], q, qinv);
+    *reinterpret_cast<u64x2 *>(o0 + 4 * p + 2) = r;
+    r.x = fp_to_canon(acc[1024 + p], q, qinv); r.y = fp_to_canon(acc[1280 + p], q, qinv);
+    *reinterpret_cast<u64x2 *>(o1 + 4 * p) = r;
+    r.x = fp_to_canon(acc[1536 + p], q, qinv); r.y = fp_to_canon(acc[1792 + p], q, qinv);
+    *reinterpret_cast<u64x2 *>(o1 + 4 * p + 2) = r;
+  }
+}
+
 // scratch limbs per ciphertext: coef L, ntt L, dec L(L+1), ksacc 2L, tsp 2, tlast 2, c01 2L
 static inline size_t fused_scratch_limbs(int nl) { return (size_t)nl * (nl + 1) + 6 * (size_t)nl + 4; }
 
@@ -646,7 +755,11 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
   if (all_fp(c)) {
     if (!dec_ready)
       hipLaunchKernelGGL(k_fused_ks_decomp_ntt_fp<LB>, dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
-    if (dec_ready == 2)
+    if (dec_ready == 2 && !std::getenv("ABC_HIP_TAILMAC_SERIAL"))
+      hipLaunchKernelGGL(k_fused_tailmac_coop_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64 * nl),
+                         (size_t)(2048 + nl * lds_words(10)) * 8, st, c->dc, (const double *)s.dec,
+                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl);
+    else if (dec_ready == 2)
       hipLaunchKernelGGL(k_fused_tailmac_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64), 0, st, c->dc, (const double *)s.dec,
                          ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl);
     else
@@ -807,7 +920,18 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     const u64 *tg = target + off * target_stride;
     const u64 *coef = tg;
     size_t coef_stride = target_stride;
-    if (ckks) {  // operand arrives in NTT form: coefficient form via one in-LDS inverse transform per limb
+    bool split = false;
+    if constexpr (LB == 14) {
+      split = all_fp(c) && !std::getenv("ABC_HIP_NO_SPLIT");
+      if (split && ckks)
+        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, true>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
+                           target_stride, (double *)s.dec, nl);
+      else if (split)
+        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
+                           target_stride, (double *)s.dec, nl);
+    }
+    if (split) {
+    } else if (ckks) {  // operand arrives in NTT form: coefficient form via one in-LDS inverse transform per limb
       if (all_fp(c))
         hipLaunchKernelGGL(k_fused_operand_intt_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
                            target_stride, s.coef, nl);
@@ -818,7 +942,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
       coef_stride = (size_t)nl * N;
     }
     if (keyswitch_stage<LB>(c, st, s, coef, coef_stride, tg, target_stride, key, addend ? addend + off * addend_stride : nullptr,
-                            addend_stride, add_c1, out + off * 2 * nl * N, nl, cc))
+                            addend_stride, add_c1, out + off * 2 * nl * N, nl, cc, split ? 2 : 0))
       return 1;
   }
   return join_lanes(c, p.lanes);

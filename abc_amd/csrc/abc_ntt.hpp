@@ -293,9 +293,11 @@ template <> struct Sched<14> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 =
 // The final register layout is PassIdx<LB, LB-2, 2>: slot r = 4g+k holds element 4*(tid + T*g) + k.
 template <int LB, class A, class Load, class Store>
 __device__ __forceinline__ void ntt_fwd_block_a(typename A::E *lds, Load load, Store store, const typename A::Table &t,
-                                                const Mod &m, int S0, int b) {
+                                                const Mod &m, int S0, int b, int tid_in = -1) {
   using SC = Sched<LB>;
-  const int tid = threadIdx.x;
+  // a 1024-point block is one wavefront: callers may run several of them side by side in one workgroup (tid_in =
+  // the lane id), so nothing in it may be a workgroup barrier
+  const int tid = tid_in < 0 ? (int)threadIdx.x : tid_in;
   const typename A::K kk = A::consts(m);
   typename A::E x[16];
   {  // pass 0: global -> regs -> LDS
@@ -310,7 +312,7 @@ __device__ __forceinline__ void ntt_fwd_block_a(typename A::E *lds, Load load, S
     fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
   }
-  block_sync_lds();
+  if constexpr (LB <= 10) wave_sync(); else block_sync_lds();
   {  // pass 1
     constexpr int S = SC::R0, R = SC::R1;
     using P = PassIdx<LB, S, R>;

@@ -1,9 +1,5 @@
+# throughput of the headline bench under different chunk / lane plans (ABC_HIP_CHUNK, ABC_HIP_LANES)
 run() { python bench.py --steps 10 --no-cpu "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(int(d['value']), round(d['roofline']['frac'],3))"; }
-echo "default b1024"; run
-echo "b2048"; run --batch 2048
-echo "b2048 chunk512"; ABC_HIP_CHUNK=512 run --batch 2048
-echo "b4096 chunk512"; ABC_HIP_CHUNK=512 run --batch 4096
-echo "b2048 chunk128 lanes4"; ABC_HIP_CHUNK=128 ABC_HIP_LANES=4 run --batch 2048
-echo "b2048 chunk256 lanes3"; ABC_HIP_CHUNK=256 ABC_HIP_LANES=3 run --batch 2048
-echo "b1024 chunk128 lanes2"; ABC_HIP_CHUNK=128 run
-echo "b1024 chunk1024 lanes1"; ABC_HIP_CHUNK=1024 ABC_HIP_LANES=1 run
+echo "default"; run
+for cfg in "64 2" "32 2" "32 4" "16 4" "64 4" "128 2" "512 2"; do set -- $cfg; echo "chunk $1 lanes $2"; ABC_HIP_CHUNK=$1 ABC_HIP_LANES=$2 run; done
+echo "default"; run
