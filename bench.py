@@ -72,10 +72,13 @@ def _cpu_worker(primes, seconds, w):
 
 def measured_traffic(batch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
-    separate runs and corrected as MI355X_MICROARCH.md prescribes; profiles/r01_pmc_traffic.json), scaled to this
+    separate runs and corrected as MI355X_MICROARCH.md prescribes; newest profiles/r*_pmc_traffic.json,
+    produced by tools/pmc_traffic.sh), scaled to this
     batch.  bench.py cannot collect PMC counters itself; None if the profile is absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        import glob
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        with open(latest) as f:
             return json.load(f)["hbm_bytes_per_mul_relin"] * batch
     except Exception:
         return None
@@ -156,13 +159,13 @@ def main():
         line = {
             "metric": "homomorphic mul+relin/sec, CKKS N=2^14", "value": value, "unit": "mul+relin/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (transforms: exact integer arithmetic in f64)", "data": "synthetic",
             "config": {"workload": "CKKS N=16384, 4 data limbs {50,40,40,40} + special 50-bit prime, ct x ct multiply + relinearize",
                        "batch_per_gpu": B, "sharding": "independent ciphertext pairs per rank, result gather only"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
-                         "kernel": "abc_hip_mul_relin = k_fused_tensor_intt + k_fused_ks_decomp_ntt (dominant) + k_fused_ks_mac + "
-                                   "k_fused_ks_special_intt + k_fused_ks_moddown",
+                         "kernel": "abc_hip_mul_relin = k_fused_tensor_pass0_fp + k_fused_tailmac_coop_fp (dominant) + "
+                                   "k_fused_ks_special_intt_fp + k_fused_ks_moddown_fp",
                          "algorithmic_bytes_per_launch": ALGO_BYTES * B, "launch_ms": launch_ms},
         }
         if not args.no_cpu and world == 1:  # CPU leg on rank 0 at N=1 only

@@ -1,0 +1,107 @@
+"""GPU parity of every kernel path the dispatcher can take for the N = 2^14 hot call.
+
+The default CKKS N=2^14 path is: fp64 transforms (all key primes < 2^50), tensor product + inverse transform + register
+pass in one kernel, single-wavefront tail transforms fused with the key inner product.  Each switch below turns one of
+those choices off (the same switches `tools/` uses for A/B timing); all variants must return the oracle's residues bit
+for bit -- on ordinary ciphertexts and on adversarial ones whose residues sit at the ends of [0, q), which is where the
+fp64 path's magnitude bounds (abc_ntt.hpp, "fp64 residue arithmetic") would break first.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+    "default": {},
+    "integer_transforms": {"ABC_HIP_NO_FP64": "1"},
+    "fp64_unsplit": {"ABC_HIP_NO_SPLIT": "1"},
+    "fp64_separate_kernels": {"ABC_HIP_NO_SPLIT": "1", "ABC_HIP_NO_TENSOR_DECOMP": "1"},
+    "fp64_split_serial_tail": {"ABC_HIP_TAILMAC_SERIAL": "1"},
+    "generic": {"ABC_HIP_NO_FUSED": "1"},
+}
+
+
+def _same(name, got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, name
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError("%s: %d/%d words differ, first at %s: got %d want %d" % (
+            name, len(bad), got.size, tuple(bad[0]), got[tuple(bad[0])], want[tuple(bad[0])]))
+
+
+def _extreme_ct(primes, nl, n, rng):
+    """a 2-component 'ciphertext' whose residues are drawn from {0, 1, (q-1)/2, (q+1)/2, q-2, q-1} and random values"""
+    ct = np.empty((2, nl, n), dtype=np.uint64)
+    for j in range(nl):
+        q = primes[j]
+        pool = np.array([0, 1, (q - 1) // 2, (q + 1) // 2, q - 2, q - 1], dtype=np.uint64)
+        pick = rng.integers(0, 8, size=(2, n))
+        rnd = rng.integers(0, q, size=(2, n), dtype=np.uint64)
+        ct[:, j, :] = np.where(pick < 6, pool[np.minimum(pick, 5)], rnd)
+    ct[0, :, : n // 4] = np.array(primes[:nl], dtype=np.uint64)[:, None] - 1  # long runs of q-1
+    return ct
+
+
+@pytest.fixture(scope="module")
+def oracle14(oracle_mod):
+    n = 16384
+    primes = oracle_mod.create_primes(n, [50, 40, 40, 40, 50])
+    o = oracle_mod.Oracle(oracle_mod.CKKS, n, primes)
+    o.keygen(0xABC00001)
+    rng = np.random.default_rng(2026)
+    x, y = rng.uniform(-1, 1, n // 2), rng.uniform(-1, 1, n // 2)
+    cx, cy = o.encrypt(o.ckks_encode(x, 2.0 ** 40), 11), o.encrypt(o.ckks_encode(y, 2.0 ** 40), 12)
+    ex, ey = _extreme_ct(primes, 4, n, rng), _extreme_ct(primes, 4, n, rng)
+    want = {
+        "mul": o.mul_relin(cx, cy),
+        "mul_extreme": o.mul_relin(ex, ey),
+        "rot": o.rotate(cx, -7),
+        "rot_extreme": o.rotate(ex, 3),
+    }
+    lvl3 = o.rescale(want["mul"])
+    want["rot_l3"] = o.rotate(lvl3, 64)
+    return o, primes, dict(cx=cx, cy=cy, ex=ex, ey=ey, lvl3=lvl3), want
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_ckks14_paths_bit_exact(variant, oracle14, capi, monkeypatch):
+    o, primes, ins, want = oracle14
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    g = capi.Context(capi.CKKS, o.n, primes)  # ABC_HIP_NO_FP64 is read when the context is built
+    g.load_keys(sk=o.secret_key(), pk=o.public_key(), relin=o.relin_key(),
+                galois={e: o.galois_key(e) for e in o.galois_elts()})
+    _same(variant + " mul_relin", g.mul_relin(ins["cx"], ins["cy"]), want["mul"])
+    _same(variant + " mul_relin extreme residues", g.mul_relin(ins["ex"], ins["ey"]), want["mul_extreme"])
+    _same(variant + " rotate", g.rotate(ins["cx"], -7), want["rot"])
+    _same(variant + " rotate extreme residues", g.rotate(ins["ex"], 3), want["rot_extreme"])
+    _same(variant + " rotate at level 3", g.rotate(ins["lvl3"], 64), want["rot_l3"])
+    # batched call: 5 pairs in one launch, mixed ordinary / extreme
+    a = np.stack([ins["cx"], ins["ex"], ins["cy"], ins["ey"], ins["cx"]])
+    b = np.stack([ins["cy"], ins["ey"], ins["cx"], ins["ex"], ins["cx"]])
+    got = g.mul_relin(a, b)
+    _same(variant + " batch[0]", got[0], want["mul"])
+    _same(variant + " batch[1]", got[1], want["mul_extreme"])
+    _same(variant + " batch[2]", got[2], o.mul_relin(ins["cy"], ins["cx"]))
+    _same(variant + " batch[3]", got[3], o.mul_relin(ins["ey"], ins["ex"]))
+    g.close()
+
+
+@pytest.mark.parametrize("variant", ["default", "integer_transforms", "fp64_unsplit"])
+def test_bfv14_keyswitch_paths_bit_exact(variant, oracle_mod, capi, monkeypatch):
+    """BFVDefault(16384): 48/49-bit primes, i.e. the re-centring ('red') fp64 butterflies, coefficient-form operand"""
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    o = oracle_mod.Oracle.bfv_default(16384)
+    o.keygen(0xABC00003)
+    g = capi.Context.bfv_default(16384)
+    g.load_keys(sk=o.secret_key(), pk=o.public_key(), relin=o.relin_key(),
+                galois={e: o.galois_key(e) for e in o.galois_elts()})
+    rng = np.random.default_rng(5)
+    nl = len(o.primes) - 1
+    ex = _extreme_ct(o.primes, nl, o.n, rng)
+    _same(variant + " bfv rotate extreme", g.rotate(ex, 1), o.rotate(ex, 1))
+    ct = o.encrypt(o.encode(oracle_mod.expand_vector([3, 1, 4, 1, 5], o.n)), 9)
+    _same(variant + " bfv mul_relin", g.mul_relin(ct, ct), o.mul_relin(ct, ct))
+    g.close()
