@@ -486,12 +486,28 @@ int abc_hip_ctx_create(int scheme, int logn, const uint64_t *primes, int nprimes
     set_error("hipEventCreate failed");
     rc = 1;
   }
-  for (int i = 0; !rc && i < abc_hip_ctx::kMaxLanes; i++)
-    if (hipEventCreateWithFlags(&c->lane_join[i], hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->lane[i], hipStreamNonBlocking) != hipSuccess) {
+  // ABC_HIP_CU_MASK=<m>: lane i may only use the CUs whose index is congruent to i modulo m (experiment: forces two
+  // lanes to run side by side, a memory-bound kernel on one half of every XCD next to an arithmetic-bound one)
+  int mask_mod = 0;
+  if (const char *e = std::getenv("ABC_HIP_CU_MASK")) mask_mod = std::atoi(e);
+  for (int i = 0; !rc && i < abc_hip_ctx::kMaxLanes; i++) {
+    hipError_t se;
+    if (mask_mod >= 2) {
+      uint32_t mask[8];
+      for (int w = 0; w < 8; w++) {
+        mask[w] = 0;
+        for (int b = 0; b < 32; b++)
+          if (((w * 32 + b) % mask_mod) == (i % mask_mod)) mask[w] |= 1u << b;
+      }
+      se = hipExtStreamCreateWithCUMask(&c->lane[i], 8, mask);
+    } else {
+      se = hipStreamCreateWithFlags(&c->lane[i], hipStreamNonBlocking);
+    }
+    if (hipEventCreateWithFlags(&c->lane_join[i], hipEventDisableTiming) != hipSuccess || se != hipSuccess) {
       set_error("lane stream / event creation failed");
       rc = 1;
     }
+  }
   if (rc) { abc_hip_ctx_destroy(c); return 1; }
   *out = c;
   return 0;
