@@ -262,6 +262,11 @@ __device__ __forceinline__ double fp_mulmod(double x, double y, double q, double
   const double c = __builtin_rint(h * qinv);
   return __builtin_fma(-c, q, h) + l;
 }
+// four consecutive words as two adjacent 16-byte stores
+__device__ __forceinline__ void store_run4(u64 *p, const u64 (&v)[4]) {
+  reinterpret_cast<u64x2 *>(p)[0] = u64x2{v[0], v[1]};
+  reinterpret_cast<u64x2 *>(p)[1] = u64x2{v[2], v[3]};
+}
 // |r| < q -> canonical u64
 __device__ __forceinline__ u64 fp_small_to_canon(double r, double q) {
   const u32 neg = (u32)((int)(u32)((u64)__double_as_longlong(r) >> 32) >> 31);
@@ -286,14 +291,20 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_intt_fp(DevCtx 
   const u64 *__restrict__ b0 = b + ct * 2 * pw + j * N, *__restrict__ b1 = b0 + pw;
   u64 *__restrict__ o0 = c01 + ct * 2 * pw + j * N, *__restrict__ o1 = o0 + pw;
   u64 *__restrict__ dcoef = c2coef + (ct * nl + j) * N, *__restrict__ dntt = c2ntt + (ct * nl + j) * N;
+  u64 t0[4], t1[4], t2[4];
   ntt_inv_block_a<LB, FpArith>(
       lds,
-      [&](int, int i) {
+      [&](int r, int i) {
         const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
-        o0[i] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
-        o1[i] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
         const double v = fp_mulmod(x1, y1, q, qinv);
-        dntt[i] = fp_small_to_canon(v, q);
+        t0[r & 3] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
+        t1[r & 3] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
+        t2[r & 3] = fp_small_to_canon(v, q);
+        if ((r & 3) == 3) {  // whole 32-byte runs, see k_fused_tensor_pass0_fp
+          store_run4(o0 + i - 3, t0);
+          store_run4(o1 + i - 3, t1);
+          store_run4(dntt + i - 3, t2);
+        }
         return v;
       },
       [&](int, int i, double v) { dcoef[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, q), q, qinv); }, t, m, 0, 0);
@@ -360,10 +371,16 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_special_intt_fp(Dev
 template <int LB>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_fp(DevCtx c, const u64 *__restrict__ ksacc,
                                                                         const u64 *__restrict__ tlast, const u64 *__restrict__ addend,
-                                                                        size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl) {
+                                                                        size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl,
+                                                                        int ncc) {
   __shared__ double lds[lds_words(LB)];
-  const int j = blockIdx.x % nl;
-  const size_t cc = blockIdx.x / nl;  // ct*2 + comp
+  // The nl workgroups that read the same special-prime polynomial (ct, comp) are 8 apart in blockIdx: workgroups go
+  // round-robin over the 8 XCDs, so they share one L2 and the polynomial is fetched from HBM once, not nl times.
+  const unsigned per = 8u * (unsigned)nl;
+  const unsigned grp = blockIdx.x / per, rem = blockIdx.x % per;
+  const unsigned left = (unsigned)ncc - grp * 8u, gsz = left < 8u ? left : 8u;  // the last group may be ragged
+  const int j = (int)(rem / gsz);
+  const size_t cc = (size_t)grp * 8 + rem % gsz;  // ct*2 + comp
   const size_t ct = cc >> 1;
   const int comp = (int)(cc & 1);
   const size_t N = (size_t)1 << LB;
@@ -460,14 +477,22 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_decomp_fp(DevCt
     const u64 *__restrict__ b0 = b + ct * 2 * pw + j * N, *__restrict__ b1 = b0 + pw;
     u64 *__restrict__ o0 = c01 + ct * 2 * pw + j * N, *__restrict__ o1 = o0 + pw;
     u64 *__restrict__ dntt = c2ntt + (ct * nl + j) * N;
+    u64 t0[4], t1[4], t2[4];
     ntt_inv_block_a<LB, FpArith>(
         lds,
-        [&](int, int i) {
+        [&](int r, int i) {
           const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
-          o0[i] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
-          o1[i] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
           const double v = fp_mulmod(x1, y1, q, qinv);
-          dntt[i] = fp_small_to_canon(v, q);
+          // a lane owns runs of four consecutive words (32 B): write each run with back-to-back 16-byte stores so the
+          // L2 sees whole sectors (halves written far apart reached HBM as two partial-sector writes: PMC WRITE_SIZE)
+          t0[r & 3] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
+          t1[r & 3] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
+          t2[r & 3] = fp_small_to_canon(v, q);
+          if ((r & 3) == 3) {
+            store_run4(o0 + i - 3, t0);
+            store_run4(o1 + i - 3, t1);
+            store_run4(dntt + i - 3, t2);
+          }
           return v;
         },
         // canonical [0, q_j) as a double: the value SEAL's decomposition reduces modulo the other primes
@@ -517,14 +542,22 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_pass0_fp(DevCtx
     const u64 *__restrict__ b0 = b + ct * 2 * pw + j * N, *__restrict__ b1 = b0 + pw;
     u64 *__restrict__ o0 = c01 + ct * 2 * pw + j * N, *__restrict__ o1 = o0 + pw;
     u64 *__restrict__ dntt = c2ntt + (ct * nl + j) * N;
+    u64 t0[4], t1[4], t2[4];
     ntt_inv_block_a<LB, FpArith>(
         lds,
-        [&](int, int i) {
+        [&](int r, int i) {
           const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
-          o0[i] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
-          o1[i] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
           const double v = fp_mulmod(x1, y1, q, qinv);
-          dntt[i] = fp_small_to_canon(v, q);
+          // a lane owns runs of four consecutive words (32 B): write each run with back-to-back 16-byte stores so the
+          // L2 sees whole sectors (halves written far apart reached HBM as two partial-sector writes: PMC WRITE_SIZE)
+          t0[r & 3] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
+          t1[r & 3] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
+          t2[r & 3] = fp_small_to_canon(v, q);
+          if ((r & 3) == 3) {
+            store_run4(o0 + i - 3, t0);
+            store_run4(o1 + i - 3, t1);
+            store_run4(dntt + i - 3, t2);
+          }
           return v;
         },
         [&](int r, int, double v) {
@@ -768,7 +801,7 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
     hipLaunchKernelGGL(k_fused_ks_special_intt_fp<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, s.tsp, s.tlast);
     if (ckks)
       hipLaunchKernelGGL(k_fused_ks_moddown_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
-                         add_c1 ? 1 : 0, out, nl);
+                         add_c1 ? 1 : 0, out, nl, (int)(cc * 2));
     else
       hipLaunchKernelGGL(k_fused_ks_moddown_bfv_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
                          add_c1 ? 1 : 0, out, nl);
