@@ -6,20 +6,29 @@
 //   SealCiphertext::multiply / multiplyInplace = Evaluator::multiply + relinearize_inplace
 //       (src/runtime/SealCiphertext.cpp:102-107,121-124)                     -> ckks_mul_relin_fused, keyswitch_fused
 //   SealCiphertext::rotateRows / rotateRowsInplace = Evaluator::rotate_rows    (:52-61) -> keyswitch_fused
-// Launch sequence of a multiply + relinearise (CKKS):
-//   K1  tensor_intt : c0 = a0b0, c1 = a0b1 + a1b0 to scratch (so `out` may alias an operand); c2 = a1b1 kept in
-//                     NTT form and, through an in-LDS inverse transform, in coefficient form (key-switch operand).
-//   K2a decomp_ntt  : workgroup (ct, key prime I, limb J) reduces operand limb J modulo key prime I and transforms
-//                     it in LDS.
-//   K2b mac         : streaming inner product with key[J][.][I] (128-bit lazy accumulation).
-//   K2c special     : the special-prime limb goes back to coefficients, plus the q_sp/2 rounding offset.
-//   K3  moddown     : workgroup (ct, comp, j): CKKS: reduce the special-prime polynomial modulo q_j, transform it,
-//                     subtract, scale by q_sp^-1, add c0 / c1.  BFV: inverse-transform the accumulated limb, then the
-//                     same subtract / scale / add in coefficient form.
-// (A single-kernel accumulate-in-registers form of K2a+K2b was measured first: 64 VGPRs of accumulators beside a
-// 16-coefficient-per-lane transform exceed the 128-VGPR budget of a 1024-thread workgroup and spill; DESIGN.md
-// "Key switch: what was tried".)
-// Algorithmic HBM bytes per multiply: 8N(6L + 2L(L+1)).
+// Three generations of the same launch sequence live here; the dispatcher (keyswitch_stage / run_mul_relin /
+// run_keyswitch) takes the first one the context's primes and ring size allow, and tests/test_gpu_paths.py holds all of
+// them bit-identical to the oracle:
+//   split fp64  (N = 2^14, every key prime < 2^50; the headline configuration)
+//       K1s tensor_pass0 / operand_pass0 : tensor product + inverse transform of c2_j in LDS, then the first radix-16
+//                                          register pass of the forward transforms modulo the other key primes;
+//                                          half-done limbs to scratch as raw doubles
+//       K2s tailmac_coop                 : wavefront J finishes limb (I, J) on a 1024-point block and multiplies into
+//                                          the key; LDS accumulators
+//       K2c special_intt_fp, K3 moddown_fp / moddown_bfv_fp
+//   un-split fp64 (N < 2^14, every key prime < 2^50)
+//       K1 tensor_decomp_fp (or tensor_intt_fp / operand_intt_fp + decomp_ntt_fp), K2b mac, K2c, K3
+//   integer     (any prime up to 61 bits)
+//       K1  tensor_intt : c0 = a0b0, c1 = a0b1 + a1b0 to scratch (so `out` may alias an operand); c2 = a1b1 kept in
+//                         NTT form and, through an in-LDS inverse transform, in coefficient form
+//       K2a decomp_ntt  : workgroup (ct, key prime I, limb J) reduces operand limb J modulo key prime I and
+//                         transforms it in LDS
+//       K2b mac         : streaming inner product with key[J][.][I] (128-bit lazy accumulation)
+//       K2c special     : the special-prime limb goes back to coefficients, plus the q_sp/2 rounding offset
+//       K3  moddown     : workgroup (ct, comp, j): CKKS: reduce the special-prime polynomial modulo q_j, transform
+//                         it, subtract, scale by q_sp^-1, add c0 / c1.  BFV: inverse-transform the accumulated limb,
+//                         then the same subtract / scale / add in coefficient form
+// Algorithmic HBM bytes per multiply: 8N(6L + 2L(L+1)); measured: DESIGN.md section 4.
 #include <cstdlib>
 
 #include "abc_context.hpp"
@@ -276,6 +285,39 @@ __device__ __forceinline__ u64 fp_small_to_canon(double r, double q) {
   return (u64)__double_as_longlong(r + 4503599627370496.0) & 0x000fffffffffffffull;
 }
 
+// CKKS tensor product of one limb, as the load functor of the inverse transform of c2: element i of (a0,a1) x (b0,b1)
+// -> c0, c1 and c2 (NTT form) to memory in whole 32-byte runs, c2 returned for the transform.  A lane owns runs of
+// four consecutive words; writing the halves of a run far apart reached HBM as two partial-sector writes (PMC
+// WRITE_SIZE 35 instead of 28 limbs per multiply), hence the staging of four values and the back-to-back stores.
+struct TensorFront {
+  const u64 *__restrict__ a0, *__restrict__ a1, *__restrict__ b0, *__restrict__ b1;
+  u64 *__restrict__ o0, *__restrict__ o1, *__restrict__ dntt;
+  double q, qinv;
+  u64 t0[4], t1[4], t2[4];
+  __device__ __forceinline__ TensorFront(const u64 *a, const u64 *b, u64 *c01, u64 *c2ntt, size_t ct, int j, int nl, size_t N,
+                                         const Mod &m)
+      : q(m.qd), qinv(m.qinv) {
+    const size_t pw = (size_t)nl * N;
+    a0 = a + ct * 2 * pw + j * N; a1 = a0 + pw;
+    b0 = b + ct * 2 * pw + j * N; b1 = b0 + pw;
+    o0 = c01 + ct * 2 * pw + j * N; o1 = o0 + pw;
+    dntt = c2ntt + (ct * nl + j) * N;
+  }
+  __device__ __forceinline__ double operator()(int r, int i) {
+    const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
+    const double v = fp_mulmod(x1, y1, q, qinv);
+    t0[r & 3] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
+    t1[r & 3] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
+    t2[r & 3] = fp_small_to_canon(v, q);
+    if ((r & 3) == 3) {
+      store_run4(o0 + i - 3, t0);
+      store_run4(o1 + i - 3, t1);
+      store_run4(dntt + i - 3, t2);
+    }
+    return v;
+  }
+};
+
 template <int LB>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_intt_fp(DevCtx c, const u64 *__restrict__ a,
                                                                          const u64 *__restrict__ b, u64 *__restrict__ c01,
@@ -283,31 +325,14 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_intt_fp(DevCtx 
   __shared__ double lds[lds_words(LB)];
   const int j = blockIdx.x % nl;
   const size_t ct = blockIdx.x / nl;
-  const size_t N = (size_t)1 << LB, pw = (size_t)nl * N;
+  const size_t N = (size_t)1 << LB;
   const Mod m = mod_at(c, j);
   const FpTable t = fp_table(c, j);
-  const double q = m.qd, qinv = m.qinv;
-  const u64 *__restrict__ a0 = a + ct * 2 * pw + j * N, *__restrict__ a1 = a0 + pw;
-  const u64 *__restrict__ b0 = b + ct * 2 * pw + j * N, *__restrict__ b1 = b0 + pw;
-  u64 *__restrict__ o0 = c01 + ct * 2 * pw + j * N, *__restrict__ o1 = o0 + pw;
-  u64 *__restrict__ dcoef = c2coef + (ct * nl + j) * N, *__restrict__ dntt = c2ntt + (ct * nl + j) * N;
-  u64 t0[4], t1[4], t2[4];
+  TensorFront front(a, b, c01, c2ntt, ct, j, nl, N, m);
+  u64 *__restrict__ dcoef = c2coef + (ct * nl + j) * N;
   ntt_inv_block_a<LB, FpArith>(
-      lds,
-      [&](int r, int i) {
-        const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
-        const double v = fp_mulmod(x1, y1, q, qinv);
-        t0[r & 3] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
-        t1[r & 3] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
-        t2[r & 3] = fp_small_to_canon(v, q);
-        if ((r & 3) == 3) {  // whole 32-byte runs, see k_fused_tensor_pass0_fp
-          store_run4(o0 + i - 3, t0);
-          store_run4(o1 + i - 3, t1);
-          store_run4(dntt + i - 3, t2);
-        }
-        return v;
-      },
-      [&](int, int i, double v) { dcoef[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, q), q, qinv); }, t, m, 0, 0);
+      lds, [&](int r, int i) { return front(r, i); },
+      [&](int, int i, double v) { dcoef[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv); }, t, m, 0, 0);
 }
 
 template <int LB>
@@ -467,38 +492,18 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_decomp_fp(DevCt
   __shared__ double lds[lds_words(LB)];
   const int j = blockIdx.x % nl;
   const size_t ct = blockIdx.x / nl;
-  const size_t N = (size_t)1 << LB, pw = (size_t)nl * N;
+  const size_t N = (size_t)1 << LB;
   double src[16];
   {
     const Mod m = mod_at(c, j);
     const FpTable t = fp_table(c, j);
-    const double q = m.qd, qinv = m.qinv;
-    const u64 *__restrict__ a0 = a + ct * 2 * pw + j * N, *__restrict__ a1 = a0 + pw;
-    const u64 *__restrict__ b0 = b + ct * 2 * pw + j * N, *__restrict__ b1 = b0 + pw;
-    u64 *__restrict__ o0 = c01 + ct * 2 * pw + j * N, *__restrict__ o1 = o0 + pw;
-    u64 *__restrict__ dntt = c2ntt + (ct * nl + j) * N;
-    u64 t0[4], t1[4], t2[4];
+    TensorFront front(a, b, c01, c2ntt, ct, j, nl, N, m);
     ntt_inv_block_a<LB, FpArith>(
-        lds,
-        [&](int r, int i) {
-          const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
-          const double v = fp_mulmod(x1, y1, q, qinv);
-          // a lane owns runs of four consecutive words (32 B): write each run with back-to-back 16-byte stores so the
-          // L2 sees whole sectors (halves written far apart reached HBM as two partial-sector writes: PMC WRITE_SIZE)
-          t0[r & 3] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
-          t1[r & 3] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
-          t2[r & 3] = fp_small_to_canon(v, q);
-          if ((r & 3) == 3) {
-            store_run4(o0 + i - 3, t0);
-            store_run4(o1 + i - 3, t1);
-            store_run4(dntt + i - 3, t2);
-          }
-          return v;
-        },
+        lds, [&](int r, int i) { return front(r, i); },
         // canonical [0, q_j) as a double: the value SEAL's decomposition reduces modulo the other primes
         [&](int r, int, double v) {
-          double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, q), q, qinv);
-          src[r] = w < 0.0 ? w + q : w;
+          const double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
+          src[r] = w < 0.0 ? w + m.qd : w;
         },
         t, m, 0, 0);
   }
@@ -531,41 +536,22 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_pass0_fp(DevCtx
   __shared__ double lds[lds_words(LB)];
   const int j = blockIdx.x % nl;
   const size_t ct = blockIdx.x / nl;
-  const size_t N = (size_t)1 << LB, pw = (size_t)nl * N;
-  const int tid = threadIdx.x;
+  const size_t N = (size_t)1 << LB;
   double src[16];
   {
     const Mod m = mod_at(c, j);
     const FpTable t = fp_table(c, j);
-    const double q = m.qd, qinv = m.qinv;
-    const u64 *__restrict__ a0 = a + ct * 2 * pw + j * N, *__restrict__ a1 = a0 + pw;
-    const u64 *__restrict__ b0 = b + ct * 2 * pw + j * N, *__restrict__ b1 = b0 + pw;
-    u64 *__restrict__ o0 = c01 + ct * 2 * pw + j * N, *__restrict__ o1 = o0 + pw;
-    u64 *__restrict__ dntt = c2ntt + (ct * nl + j) * N;
-    u64 t0[4], t1[4], t2[4];
+    TensorFront front(a, b, c01, c2ntt, ct, j, nl, N, m);
     ntt_inv_block_a<LB, FpArith>(
-        lds,
-        [&](int r, int i) {
-          const double x0 = fp_from_u64(a0[i]), x1 = fp_from_u64(a1[i]), y0 = fp_from_u64(b0[i]), y1 = fp_from_u64(b1[i]);
-          const double v = fp_mulmod(x1, y1, q, qinv);
-          // a lane owns runs of four consecutive words (32 B): write each run with back-to-back 16-byte stores so the
-          // L2 sees whole sectors (halves written far apart reached HBM as two partial-sector writes: PMC WRITE_SIZE)
-          t0[r & 3] = fp_small_to_canon(fp_mulmod(x0, y0, q, qinv), q);
-          t1[r & 3] = fp_to_canon(fp_mulmod(x0, y1, q, qinv) + fp_mulmod(x1, y0, q, qinv), q, qinv);
-          t2[r & 3] = fp_small_to_canon(v, q);
-          if ((r & 3) == 3) {
-            store_run4(o0 + i - 3, t0);
-            store_run4(o1 + i - 3, t1);
-            store_run4(dntt + i - 3, t2);
-          }
-          return v;
-        },
+        lds, [&](int r, int i) { return front(r, i); },
+        // canonical [0, q_j) as a double: the value SEAL's decomposition reduces modulo the other primes
         [&](int r, int, double v) {
-          double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, q), q, qinv);
-          src[r] = w < 0.0 ? w + q : w;
+          const double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
+          src[r] = w < 0.0 ? w + m.qd : w;
         },
         t, m, 0, 0);
   }
+  const int tid = threadIdx.x;
   const int hi0[1] = {0};
   for (int I = 0; I <= nl; I++) {
     if (I == j) continue;
@@ -862,10 +848,21 @@ static ChunkPlan plan_chunks(const abc_hip_ctx *c, int nl, size_t count) {
   return p;
 }
 
+// one wavefront that sleeps for `ticks` of the 100 MHz wall clock (lane phase offset experiment)
+__global__ void k_lane_delay(unsigned ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 static int fork_lanes(abc_hip_ctx *c, int lanes) {
   if (lanes < 2) return 0;
   ABC_HIP_CHECK(hipEventRecord(c->lane_fork, c->stream));
   for (int l = 0; l < lanes; l++) ABC_HIP_CHECK(hipStreamWaitEvent(c->lane[l], c->lane_fork, 0));
+  // ABC_HIP_LANE_OFFSET_US: lane l starts l x this late, so that the lanes sit in different kernels of the sequence
+  if (const char *e = std::getenv("ABC_HIP_LANE_OFFSET_US")) {
+    const unsigned us = (unsigned)std::atoi(e);
+    for (int l = 1; l < lanes && us; l++) hipLaunchKernelGGL(k_lane_delay, dim3(1), dim3(64), 0, c->lane[l], us * 100u * l);
+  }
   return 0;
 }
 static int join_lanes(abc_hip_ctx *c, int lanes) {
