@@ -774,7 +774,8 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
   if (all_fp(c)) {
     if (!dec_ready)
       hipLaunchKernelGGL(k_fused_ks_decomp_ntt_fp<LB>, dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
-    if (dec_ready == 2 && !std::getenv("ABC_HIP_TAILMAC_SERIAL"))
+    // cooperative form: nl wavefronts and 16 + 8.5 nl KiB of LDS per workgroup
+    if (dec_ready == 2 && nl <= 12 && !std::getenv("ABC_HIP_TAILMAC_SERIAL"))
       hipLaunchKernelGGL(k_fused_tailmac_coop_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64 * nl),
                          (size_t)(2048 + nl * lds_words(10)) * 8, st, c->dc, (const double *)s.dec,
                          ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl);
