@@ -204,19 +204,26 @@ static int build_context(abc_hip_ctx *c) {
       const uint64_t q = qs[i];
       k.mtilde_mod_q[i] = mt % q;
       k.inv_punct_q[i] = invmod(punct_mod(qs, i, q), q);
-      for (int j = 0; j < nBsk; j++) k.q_to_bsk[j][i] = punct_mod(qs, i, bsk[j]);
+      for (int j = 0; j < nBsk; j++) {
+        k.q_to_bsk[j][i] = punct_mod(qs, i, bsk[j]);
+        k.q_to_bsk_s[j][i] = shoup(k.q_to_bsk[j][i], bsk[j]);
+      }
       k.q_to_mtilde[i] = punct_mod(qs, i, mt);
       k.q_to_t[i] = punct_mod(qs, i, t);
       k.q_to_gamma[i] = punct_mod(qs, i, gamma);
       k.B_mod_q[i] = prod_mod(Bp, q);
       k.t_mod_q[i] = t % q;
       k.tgamma_mod_q[i] = mulmod(t % q, gamma % q, q);
-      for (int b = 0; b < nB; b++) k.B_to_q[i][b] = punct_mod(Bp, b, q);
+      for (int b = 0; b < nB; b++) {
+        k.B_to_q[i][b] = punct_mod(Bp, b, q);
+        k.B_to_q_s[i][b] = shoup(k.B_to_q[i][b], q);
+      }
     }
     k.neg_inv_q_mod_mtilde = negmod(invmod(prod_mod(qs, mt), mt), mt);
     for (int j = 0; j < nBsk; j++) {
       const uint64_t p = bsk[j];
       k.q_mod_bsk[j] = prod_mod(qs, p);
+      k.q_mod_bsk_s[j] = shoup(k.q_mod_bsk[j], p);
       k.inv_q_mod_bsk[j] = invmod(k.q_mod_bsk[j], p);
       k.inv_mtilde_mod_bsk[j] = invmod(mt % p, p);
       k.t_mod_bsk[j] = t % p;
@@ -224,6 +231,7 @@ static int build_context(abc_hip_ctx *c) {
     for (int b = 0; b < nB; b++) {
       k.inv_punct_B[b] = invmod(punct_mod(Bp, b, Bp[b]), Bp[b]);
       k.B_to_msk[b] = punct_mod(Bp, b, m_sk);
+      k.B_to_msk_s[b] = shoup(k.B_to_msk[b], m_sk);
     }
     k.inv_B_mod_msk = invmod(prod_mod(Bp, m_sk), m_sk);
     k.inv_B_mod_msk_s = shoup(k.inv_B_mod_msk, m_sk);

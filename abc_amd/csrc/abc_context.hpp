@@ -49,6 +49,8 @@ struct DevConst {
   u64 inv_q_mod_bsk_s[kMaxLimbs], inv_mtilde_mod_bsk_s[kMaxLimbs], inv_punct_B_s[kMaxLimbs];
   u64 inv_B_mod_msk_s, B_mod_q_s[kMaxLimbs];
   u64 dec_q[kMaxLimbs], dec_q_s[kMaxLimbs];          // t*gamma * (q/q_i)^-1 mod q_i     (decrypt)
+  // Shoup quotients of the base-conversion matrices (lazy dot products: one mulhi per term, no 128-bit sums)
+  u64 q_to_bsk_s[kMaxLimbs][kMaxLimbs], B_to_q_s[kMaxLimbs][kMaxLimbs], B_to_msk_s[kMaxLimbs], q_mod_bsk_s[kMaxLimbs];
   // BFV decryption (decrypt_scale_and_round)
   u64 tgamma_mod_q[kMaxLimbs], q_to_t[kMaxLimbs], q_to_gamma[kMaxLimbs];
   u64 neg_inv_q_mod_t, neg_inv_q_mod_gamma, inv_gamma_mod_t, gamma;

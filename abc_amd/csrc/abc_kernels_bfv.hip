@@ -36,32 +36,57 @@ __device__ __forceinline__ u64 dot_mod(int n, FA a, FB b, const Mod &m) {
   return res;
 }
 
+// Same sum with precomputed Shoup quotients of the constants: every term is one lazy Shoup product in [0, 2q) (any
+// 64-bit operand), summed in 64 bits -- no 128-bit accumulator, no Barrett per group.  The running sum is brought
+// back below 2q after every fourth term where 8q could pass 2^64 (q of 59..61 bits: the BEHZ auxiliary primes);
+// smaller moduli take up to 32 terms unreduced.  Returns a lazy value: < 2q if FLUSH else < 2nq (callers feed it to
+// mul_shoup, which accepts any 64-bit operand, or reduce it with reduce64 / canon_lazy2).
+template <class FA, class FW, class FS>
+__device__ __forceinline__ u64 dot_shoup_lazy(int n, FA a, FW w, FS ws, const Mod &m) {
+  const bool flush = m.bits > 58;
+  u64 acc = 0;
+#pragma unroll
+  for (int i = 0; i < n; i++) {
+    acc += mul_shoup_lazy(a(i), w(i), ws(i), m.q);
+    if (flush && (i & 3) == 3) acc = csub(csub(acc, m.two_q << 1), m.two_q);  // < 8q -> < 2q
+  }
+  if (flush) acc = csub(csub(acc, m.two_q << 1), m.two_q);
+  return acc;
+}
+// lazy value of dot_shoup_lazy -> [0, q)
+__device__ __forceinline__ u64 canon_dot(u64 v, const Mod &m) { return m.bits > 58 ? csub(v, m.q) : reduce64(v, m); }
+
 // ---- BEHZ steps (1)-(2): q -> Bsk with Montgomery reduction of the q-overflow ----
 // in: [polys][L][N] coefficient form; out: [polys][nBsk][N]
+// LT > 0: limb counts known at compile time (L = LT, nBsk = NBT + 1), so every loop unrolls and the conversion
+// constants arrive in batched scalar loads instead of one dependent s_load per inner iteration (the runtime-bound
+// form is latency-bound on exactly that: 0.94 ms -> see DESIGN.md).  LT = 0: any shape.
+template <int LT, int NBT>
 __global__ __launch_bounds__(256) void k_behz_extend(DevCtx c, const u64 *in, u64 *out, size_t polys) {
-  const DevConst &k = *c.cst;
-  const int L = k.nq, nBsk = k.nBsk;
+  const ABC_CONST_AS DevConst &k = *(const ABC_CONST_AS DevConst *)c.cst;  // constants never change: scalar loads
+  const int L = LT ? LT : k.nq, nBsk = LT ? NBT + 1 : k.nBsk;
   const size_t items = polys * c.n;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
     const size_t p = it >> c.logn, x = it & (c.n - 1);
-    u64 tmp[kMaxLimbs];
+    u64 tmp[LT ? LT : kMaxLimbs];
     u32 mt = 0;
+#pragma unroll
     for (int i = 0; i < L; i++) {
       // * m~ * (q/q_i)^-1 as one constant (canonical result, so identical to the two-step product)
-      const u64 v = mul_shoup(in[(p * L + i) * c.n + x], k.ext_q[i], k.ext_q_s[i], c.mods[i].q);
+      const u64 v = mul_shoup(in[(p * L + i) * c.n + x], k.ext_q[i], k.ext_q_s[i], mod_at(c, i).q);
       tmp[i] = v;
       mt += (u32)v * (u32)k.q_to_mtilde[i];  // arithmetic mod 2^32
     }
     const u32 r32 = mt * (u32)k.neg_inv_q_mod_mtilde;
+#pragma unroll
     for (int j = 0; j < nBsk; j++) {
-      const Mod m = c.mods[c.id_bsk + j];
-      const u64 conv = dot_mod(L, [&](int i) { return tmp[i]; }, [&](int i) { return k.q_to_bsk[j][i]; }, m);
+      const Mod m = mod_at(c, c.id_bsk + j);
+      const u64 conv = dot_shoup_lazy(L, [&](int i) { return tmp[i]; }, [&](int i) { return k.q_to_bsk[j][i]; },
+                                      [&](int i) { return k.q_to_bsk_s[j][i]; }, m);  // < 2p
       u64 r = r32;
       if (r32 >= 0x80000000u) r += m.q - 0x100000000ull;  // centred representative of r mod m~
-      U128 acc = mul_wide(r, k.q_mod_bsk[j]);
-      add128(acc, U128{conv, 0});
-      const u64 v = barrett_reduce(acc, m);
+      const u64 v = conv + mul_shoup_lazy(r, k.q_mod_bsk[j], k.q_mod_bsk_s[j], m.q);  // < 4p < 2^64
       out[(p * nBsk + j) * c.n + x] = mul_shoup(v, k.inv_mtilde_mod_bsk[j], k.inv_mtilde_mod_bsk_s[j], m.q);
     }
   }
@@ -87,38 +112,65 @@ __global__ __launch_bounds__(256) void k_tensor_map(DevCtx c, const u64 *a, cons
 
 // ---- BEHZ steps (6)-(8): scale by t, fast floor by q, Shenoy-Kumaresan back to q ----
 // dq [polys][L][N], dB [polys][nBsk][N] (coefficient form) -> out [polys][L][N]
+template <int LT, int NBT>
 __global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, const u64 *dB, u64 *out, size_t polys) {
-  const DevConst &k = *c.cst;
-  const int L = k.nq, nB = k.nB, nBsk = k.nBsk;
+  const ABC_CONST_AS DevConst &k = *(const ABC_CONST_AS DevConst *)c.cst;  // constants never change: scalar loads
+  const int L = LT ? LT : k.nq, nB = LT ? NBT : k.nB, nBsk = nB + 1;
   const size_t items = polys * c.n;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const Mod msk = c.mods[c.id_bsk + nB];
+  const Mod msk = mod_at(c, c.id_bsk + nB);
   for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
     const size_t p = it >> c.logn, x = it & (c.n - 1);
-    u64 tq[kMaxLimbs], fl[kMaxLimbs];
+    u64 tq[LT ? LT : kMaxLimbs], fl[LT ? NBT + 1 : kMaxLimbs + 1];
+#pragma unroll
     for (int i = 0; i < L; i++) {
-      tq[i] = mul_shoup(dq[(p * L + i) * c.n + x], k.flr_q[i], k.flr_q_s[i], c.mods[i].q);  // * t * (q/q_i)^-1
+      // * t * (q/q_i)^-1; canonical: the conversion below sums these residues as INTEGERS in [0, q_i)
+      tq[i] = mul_shoup(dq[(p * L + i) * c.n + x], k.flr_q[i], k.flr_q_s[i], mod_at(c, i).q);
     }
+#pragma unroll
     for (int j = 0; j < nBsk; j++) {
-      const Mod m = c.mods[c.id_bsk + j];
-      const u64 conv = dot_mod(L, [&](int i) { return tq[i]; }, [&](int i) { return k.q_to_bsk[j][i]; }, m);
+      const Mod m = mod_at(c, c.id_bsk + j);
+      const u64 conv = dot_shoup_lazy(L, [&](int i) { return tq[i]; }, [&](int i) { return k.q_to_bsk[j][i]; },
+                                      [&](int i) { return k.q_to_bsk_s[j][i]; }, m);
       // (dB*t - conv) * q^-1 = dB*(t q^-1) - conv*q^-1   (both constants carry Shoup quotients)
       const u64 xb = mul_shoup(dB[(p * nBsk + j) * c.n + x], k.tinvq_bsk[j], k.tinvq_bsk_s[j], m.q);
       fl[j] = sub_mod(xb, mul_shoup(conv, k.inv_q_mod_bsk[j], k.inv_q_mod_bsk_s[j], m.q), m.q);
     }
-    u64 tb[kMaxLimbs];
-    for (int b2 = 0; b2 < nB; b2++) tb[b2] = mul_shoup(fl[b2], k.inv_punct_B[b2], k.inv_punct_B_s[b2], c.mods[c.id_bsk + b2].q);
-    const u64 msk_conv = dot_mod(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_msk[b2]; }, msk);
+    u64 tb[LT ? NBT : kMaxLimbs];
+#pragma unroll
+    for (int b2 = 0; b2 < nB; b2++) tb[b2] = mul_shoup(fl[b2], k.inv_punct_B[b2], k.inv_punct_B_s[b2], mod_at(c, c.id_bsk + b2).q);
+    const u64 msk_conv = canon_dot(dot_shoup_lazy(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_msk[b2]; },
+                                                  [&](int b2) { return k.B_to_msk_s[b2]; }, msk), msk);
     const u64 alpha = mul_shoup(sub_mod(msk_conv, fl[nB], msk.q), k.inv_B_mod_msk, k.inv_B_mod_msk_s, msk.q);
     const bool neg = alpha > (msk.q >> 1);
+#pragma unroll
     for (int i = 0; i < L; i++) {
-      const Mod m = c.mods[i];
-      u64 v = dot_mod(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_q[i][b2]; }, m);
-      if (neg) v = add_mod(v, mul_shoup(msk.q - alpha, k.B_mod_q[i], k.B_mod_q_s[i], m.q), m.q);
-      else v = sub_mod(v, mul_shoup(alpha, k.B_mod_q[i], k.B_mod_q_s[i], m.q), m.q);
-      out[(p * L + i) * c.n + x] = v;
+      const Mod m = mod_at(c, i);
+      u64 v = dot_shoup_lazy(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_q[i][b2]; },
+                             [&](int b2) { return k.B_to_q_s[i][b2]; }, m);
+      // +- alpha * B: one more lazy term (the subtraction as 2q - term keeps the sum non-negative)
+      const u64 ab = mul_shoup_lazy(neg ? msk.q - alpha : alpha, k.B_mod_q[i], k.B_mod_q_s[i], m.q);
+      v = neg ? v + ab : v + m.two_q - ab;
+      if (m.bits > 58) v = csub(v, m.two_q);  // v < 2q + 2q there
+      out[(p * L + i) * c.n + x] = canon_dot(v, m);
     }
   }
+}
+
+// shapes of BFVDefault(4096 / 8192 / 16384) and of config 5 get fully unrolled kernels
+#define ABC_BEHZ_DISPATCH(KERNEL, GRID, ...)                                                                          \
+  do {                                                                                                                  \
+    const int L_ = c->L, nB_ = c->nB;                                                                                   \
+    if (L_ == 2 && nB_ == 2) hipLaunchKernelGGL((KERNEL<2, 2>), GRID, dim3(256), 0, c->stream, __VA_ARGS__);            \
+    else if (L_ == 4 && nB_ == 4) hipLaunchKernelGGL((KERNEL<4, 4>), GRID, dim3(256), 0, c->stream, __VA_ARGS__);       \
+    else if (L_ == 8 && nB_ == 8) hipLaunchKernelGGL((KERNEL<8, 8>), GRID, dim3(256), 0, c->stream, __VA_ARGS__);       \
+    else hipLaunchKernelGGL((KERNEL<0, 0>), GRID, dim3(256), 0, c->stream, __VA_ARGS__);                                \
+  } while (0)
+static void launch_behz_extend(abc_hip_ctx *c, const u64 *in, u64 *out, size_t polys) {
+  ABC_BEHZ_DISPATCH(k_behz_extend, dim3(grid_for(polys * c->n, 256)), c->dc, in, out, polys);
+}
+static void launch_behz_floor(abc_hip_ctx *c, const u64 *dq, const u64 *dB, u64 *out, size_t polys) {
+  ABC_BEHZ_DISPATCH(k_behz_floor, dim3(grid_for(polys * c->n, 256)), c->dc, dq, dB, out, polys);
 }
 
 int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t count) {
@@ -145,8 +197,8 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
     const size_t in_bytes = cc * 2 * L * N * 8;
     ABC_HIP_CHECK(hipMemcpyAsync(aq, pa, in_bytes, hipMemcpyDeviceToDevice, c->stream));
     ABC_HIP_CHECK(hipMemcpyAsync(bq, pb, in_bytes, hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(k_behz_extend, dim3(grid_for(cc * 2 * N, 256)), dim3(256), 0, c->stream, c->dc, pa, aB, cc * 2);
-    hipLaunchKernelGGL(k_behz_extend, dim3(grid_for(cc * 2 * N, 256)), dim3(256), 0, c->stream, c->dc, pb, bB, cc * 2);
+    launch_behz_extend(c, pa, aB, cc * 2);
+    launch_behz_extend(c, pb, bB, cc * 2);
     ABC_HIP_CHECK(hipGetLastError());
     if (launch_ntt_fwd(c, aq, qmap, L, cc * 4 * L)) return 1;          // aq and bq are adjacent
     if (launch_ntt_fwd(c, aB, bmap, nBsk, cc * 4 * nBsk)) return 1;    // aB and bB are adjacent
@@ -156,8 +208,7 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
     ABC_HIP_CHECK(hipGetLastError());
     if (launch_ntt_inv(c, dq, qmap, L, cc * 3 * L)) return 1;
     if (launch_ntt_inv(c, dB, bmap, nBsk, cc * 3 * nBsk)) return 1;
-    hipLaunchKernelGGL(k_behz_floor, dim3(grid_for(cc * 3 * N, 256)), dim3(256), 0, c->stream, c->dc, dq, dB,
-                       out3 + off * 3 * L * N, cc * 3);
+    launch_behz_floor(c, dq, dB, out3 + off * 3 * L * N, cc * 3);
     ABC_HIP_CHECK(hipGetLastError());
   }
   return 0;
