@@ -194,13 +194,11 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
   for (size_t off = 0; off < count; off += chunk) {
     const size_t cc = (count - off < chunk) ? count - off : chunk;
     const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
-    const size_t in_bytes = cc * 2 * L * N * 8;
-    ABC_HIP_CHECK(hipMemcpyAsync(aq, pa, in_bytes, hipMemcpyDeviceToDevice, c->stream));
-    ABC_HIP_CHECK(hipMemcpyAsync(bq, pb, in_bytes, hipMemcpyDeviceToDevice, c->stream));
     launch_behz_extend(c, pa, aB, cc * 2);
     launch_behz_extend(c, pb, bB, cc * 2);
     ABC_HIP_CHECK(hipGetLastError());
-    if (launch_ntt_fwd(c, aq, qmap, L, cc * 4 * L)) return 1;          // aq and bq are adjacent
+    if (launch_ntt_fwd_from(c, pa, aq, qmap, L, cc * 2 * L)) return 1;  // operands stay intact: transform out of place
+    if (launch_ntt_fwd_from(c, pb, bq, qmap, L, cc * 2 * L)) return 1;
     if (launch_ntt_fwd(c, aB, bmap, nBsk, cc * 4 * nBsk)) return 1;    // aB and bB are adjacent
     hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * L * N, 256)), dim3(256), 0, c->stream, c->dc, aq, bq, dq, qmap, L, cc);
     hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * nBsk * N, 256)), dim3(256), 0, c->stream, c->dc, aB, bB, dB, bmap, nBsk,

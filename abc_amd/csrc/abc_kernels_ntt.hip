@@ -11,7 +11,7 @@
 namespace abc {
 
 template <int LB, bool GUARD>
-__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data, LimbMap map, int nl, int S0) {
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data, const u64 *src, LimbMap map, int nl, int S0) {
   __shared__ u64 lds[lds_words(LB)];
   const size_t limb = blockIdx.x >> S0;
   const int b = blockIdx.x & ((1 << S0) - 1);
@@ -19,8 +19,9 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data,
   const Mod m = c.mods[mid];
   const NttTable t = ntt_table(c, mid);
   u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
+  const u64 *in = src + limb * (size_t)c.n + ((size_t)b << LB);  // == base for an in-place transform
   ntt_fwd_block<LB, GUARD>(
-      lds, [&](int, int i) { return base[i]; }, [&](int, int i, u64 v) { base[i] = canon_fwd<GUARD>(v, m); }, t, m, S0, b);
+      lds, [&](int, int i) { return in[i]; }, [&](int, int i, u64 v) { base[i] = canon_fwd<GUARD>(v, m); }, t, m, S0, b);
 }
 
 template <int LB>
@@ -41,15 +42,16 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv(DevCtx c, u64 *data,
 // fp64 variants (every prime of the launch below 2^50, whole transform in one block): same memory format, the
 // conversion u64 <-> double happens in the load / store functors.
 template <int LB>
-__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd_fp(DevCtx c, u64 *data, LimbMap map, int nl) {
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd_fp(DevCtx c, u64 *data, const u64 *src, LimbMap map, int nl) {
   __shared__ double lds[lds_words(LB)];
   const size_t limb = blockIdx.x;
   const int mid = map.id[limb % nl];
   const Mod m = c.mods[mid];
   const FpTable t = fp_table(c, mid);
   u64 *base = data + limb * (size_t)c.n;
+  const u64 *in = src + limb * (size_t)c.n;  // == base for an in-place transform
   ntt_fwd_block_a<LB, FpArith>(
-      lds, [&](int, int i) { return fp_from_u64(base[i]); }, [&](int, int i, double v) { base[i] = fp_to_canon(v, m.qd, m.qinv); },
+      lds, [&](int, int i) { return fp_from_u64(in[i]); }, [&](int, int i, double v) { base[i] = fp_to_canon(v, m.qd, m.qinv); },
       t, m, 0, 0);
 }
 
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(256) void k_ntt_inv_strided(DevCtx c, u64 *data, Li
 constexpr int kBigBlockLB = 12;  // LDS block size used under the strided pass for N > 2^14
 
 template <int LB>
-static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, int S0, bool fwd) {
+static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, int S0, bool fwd,
+                        const u64 *src = nullptr) {
+  if (!src) src = d;
   dim3 grid((unsigned)(total_limbs << S0)), block((1 << LB) / 16);
   // every limb of the launch must allow the unguarded butterflies; the strided pre-pass (S0 > 0) already
   // spent part of the headroom, keep the guard there
@@ -143,13 +147,13 @@ static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size
     fp = fp && fp_ok(c->h_mods[map.id[j]].bits);
   }
   if (fp && fwd)
-    hipLaunchKernelGGL(k_ntt_fwd_fp<LB>, grid, block, 0, c->stream, c->dc, d, map, nl);
+    hipLaunchKernelGGL(k_ntt_fwd_fp<LB>, grid, block, 0, c->stream, c->dc, d, src, map, nl);
   else if (fp)
     hipLaunchKernelGGL(k_ntt_inv_fp<LB>, grid, block, 0, c->stream, c->dc, d, map, nl);
   else if (fwd && guard)
-    hipLaunchKernelGGL((k_ntt_fwd<LB, true>), grid, block, 0, c->stream, c->dc, d, map, nl, S0);
+    hipLaunchKernelGGL((k_ntt_fwd<LB, true>), grid, block, 0, c->stream, c->dc, d, src, map, nl, S0);
   else if (fwd)
-    hipLaunchKernelGGL((k_ntt_fwd<LB, false>), grid, block, 0, c->stream, c->dc, d, map, nl, S0);
+    hipLaunchKernelGGL((k_ntt_fwd<LB, false>), grid, block, 0, c->stream, c->dc, d, src, map, nl, S0);
   else
     hipLaunchKernelGGL(k_ntt_inv<LB>, grid, block, 0, c->stream, c->dc, d, map, nl, S0);
   ABC_HIP_CHECK(hipGetLastError());
@@ -168,14 +172,20 @@ static int launch_strided(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, si
   return 0;
 }
 
-static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd) {
+// src != nullptr (forward only): read the coefficients from src, write the transform to d (saves a copy where the
+// operand must survive); rings that need the strided pre-pass copy first.
+static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd, const u64 *src = nullptr) {
   if (total_limbs == 0) return 0;
+  if (src && (c->logn > 14 || !fwd)) {
+    ABC_HIP_CHECK(hipMemcpyAsync(d, src, total_limbs * (size_t)c->n * 8, hipMemcpyDeviceToDevice, c->stream));
+    src = nullptr;
+  }
   switch (c->logn) {
-    case 10: return launch_block<10>(c, d, map, nl, total_limbs, 0, fwd);
-    case 11: return launch_block<11>(c, d, map, nl, total_limbs, 0, fwd);
-    case 12: return launch_block<12>(c, d, map, nl, total_limbs, 0, fwd);
-    case 13: return launch_block<13>(c, d, map, nl, total_limbs, 0, fwd);
-    case 14: return launch_block<14>(c, d, map, nl, total_limbs, 0, fwd);
+    case 10: return launch_block<10>(c, d, map, nl, total_limbs, 0, fwd, src);
+    case 11: return launch_block<11>(c, d, map, nl, total_limbs, 0, fwd, src);
+    case 12: return launch_block<12>(c, d, map, nl, total_limbs, 0, fwd, src);
+    case 13: return launch_block<13>(c, d, map, nl, total_limbs, 0, fwd, src);
+    case 14: return launch_block<14>(c, d, map, nl, total_limbs, 0, fwd, src);
     case 15:
     case 16: {
       const int S0 = c->logn - kBigBlockLB;
@@ -199,6 +209,9 @@ static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t
 
 int launch_ntt_fwd(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
   return launch_ntt(c, d, map, nl, total_limbs, true);
+}
+int launch_ntt_fwd_from(abc_hip_ctx *c, const u64 *src, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
+  return launch_ntt(c, d, map, nl, total_limbs, true, src);
 }
 int launch_ntt_inv(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
   return launch_ntt(c, d, map, nl, total_limbs, false);

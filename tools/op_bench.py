@@ -71,6 +71,16 @@ def main():
         ms = timeit(g, lambda: g.op("mul_relin", a.ptr, b.ptr, out.ptr, L, one), reps=20)
         res["bfv%d_mul_relin_latency_ms" % n] = ms
         print("%-40s %8.3f ms (batch 1)" % ("bfv%d_mul_relin latency" % n, ms), flush=True)
+        # the same call replayed from a captured HIP graph (abc_hip_graph_*)
+        g.op("mul_relin", a.ptr, b.ptr, out.ptr, L, one)  # scratch arenas sized before capture
+        g.sync()
+        g.graph_begin()
+        g.op("mul_relin", a.ptr, b.ptr, out.ptr, L, one)
+        ge = g.graph_end()
+        ms = timeit(g, lambda: g.graph_launch(ge), reps=20)
+        g.graph_destroy(ge)
+        res["bfv%d_mul_relin_graph_latency_ms" % n] = ms
+        print("%-40s %8.3f ms (batch 1, HIP graph replay)" % ("bfv%d_mul_relin latency" % n, ms), flush=True)
         del a, b, out
         g.close()
     os.makedirs("gpurun_out", exist_ok=True)
