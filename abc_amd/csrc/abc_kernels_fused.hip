@@ -574,12 +574,16 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_pass0_fp(DevCtx
 // prime including q_j itself.
 template <int LB, bool CKKS>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCtx c, const u64 *__restrict__ src, size_t src_stride,
-                                                                           double *__restrict__ part, int nl) {
+                                                                           double *__restrict__ part, int nl, int per_target) {
   static_assert(LB == 14, "split transforms are laid out for N = 2^14");
   __shared__ double lds[CKKS ? lds_words(LB) : 1];
   const size_t N = (size_t)1 << LB;
-  const int j = blockIdx.x % nl;
-  const size_t ct = blockIdx.x / nl;
+  // per_target (BFV, few ciphertexts in flight): one workgroup per (ct, J, target I) instead of per (ct, J), so a
+  // single-ciphertext call spreads over nl (nl+1) CUs rather than nl
+  const unsigned wg = per_target ? blockIdx.x / (unsigned)(nl + 1) : blockIdx.x;
+  const int only = per_target ? (int)(blockIdx.x % (unsigned)(nl + 1)) : -1;
+  const int j = wg % nl;
+  const size_t ct = wg / nl;
   const int tid = threadIdx.x;
   const u64 *__restrict__ sp = src + ct * src_stride + (size_t)j * N;
   double x[16];
@@ -600,6 +604,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCt
   const int hi0[1] = {0};
   for (int I = 0; I <= nl; I++) {
     if (CKKS && I == j) continue;
+    if (only >= 0 && I != only) continue;
     const int ki = (I == nl) ? c.K - 1 : I;
     const Mod m = mod_at(c, ki);
     const FpTable t = fp_table(c, ki);
@@ -956,10 +961,13 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
       split = all_fp(c) && !std::getenv("ABC_HIP_NO_SPLIT");
       if (split && ckks)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, true>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
-                           target_stride, (double *)s.dec, nl);
+                           target_stride, (double *)s.dec, nl, 0);
+      else if (split && cc * nl < 128)
+        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false>), dim3((unsigned)(cc * nl * (nl + 1))), dim3((1 << LB) / 16), 0, st,
+                           c->dc, tg, target_stride, (double *)s.dec, nl, 1);
       else if (split)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
-                           target_stride, (double *)s.dec, nl);
+                           target_stride, (double *)s.dec, nl, 0);
     }
     if (split) {
     } else if (ckks) {  // operand arrives in NTT form: coefficient form via one in-LDS inverse transform per limb

@@ -6,6 +6,8 @@
 // pass per limb.  N = 2^15, 2^16: a strided register pass through HBM does the first (forward) / last
 // (inverse) logN-12 stages, then 4096-point LDS blocks do the rest -- no transpose is needed because the
 // Cooley-Tukey bit-reversed-output ordering keeps later stages block-local.
+#include <cstdlib>
+
 #include "abc_context.hpp"
 
 namespace abc {
@@ -185,7 +187,23 @@ static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t
     case 11: return launch_block<11>(c, d, map, nl, total_limbs, 0, fwd, src);
     case 12: return launch_block<12>(c, d, map, nl, total_limbs, 0, fwd, src);
     case 13: return launch_block<13>(c, d, map, nl, total_limbs, 0, fwd, src);
-    case 14: return launch_block<14>(c, d, map, nl, total_limbs, 0, fwd, src);
+    case 14: {
+      // few limbs in flight (single-ciphertext calls): one workgroup per limb leaves most CUs idle for 17-30 us per
+      // transform; spread each transform over 64 + 16 workgroups instead (strided radix-16 pass through HBM +
+      // 1024-point blocks, the N > 2^14 machinery), trading an HBM round trip nobody misses at this size
+      static const size_t few = std::getenv("ABC_HIP_FEW_LIMBS") ? (size_t)std::atol(std::getenv("ABC_HIP_FEW_LIMBS")) : 48;
+      if (total_limbs > few) return launch_block<14>(c, d, map, nl, total_limbs, 0, fwd, src);
+      if (src) {
+        ABC_HIP_CHECK(hipMemcpyAsync(d, src, total_limbs * (size_t)c->n * 8, hipMemcpyDeviceToDevice, c->stream));
+        src = nullptr;
+      }
+      if (fwd) {
+        if (int rc = launch_strided<4>(c, d, map, nl, total_limbs, true)) return rc;
+        return launch_block<10>(c, d, map, nl, total_limbs, 4, true);
+      }
+      if (int rc = launch_block<10>(c, d, map, nl, total_limbs, 4, false)) return rc;
+      return launch_strided<4>(c, d, map, nl, total_limbs, false);
+    }
     case 15:
     case 16: {
       const int S0 = c->logn - kBigBlockLB;
