@@ -49,6 +49,11 @@ def main():
         res[name] = {"ms": ms, "us_per_transform_per_cu": ms * 1e3 / 4096 * 256}
         print("%-26s %8.3f ms  %6.2f us per transform per CU  (%.0f GB/s if 256 KiB per transform)" %
               (name, ms, ms * 1e3 / 4096 * 256, 4096 * 262144 / ms / 1e6), flush=True)
+    # can arithmetic and HBM streaming overlap at chip level?  fp64 FMA kernel and 1 GiB-per-pass copy, alone / together
+    for which, name in ((320, "fma_only"), (321, "copy_only"), (322, "fma_and_copy_concurrent")):
+        ms = g.microbench(which, 8)
+        res[name] = {"ms": ms}
+        print("%-26s %8.3f ms" % (name, ms), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/microbench.json", "w") as f:
         json.dump(res, f, indent=1)
