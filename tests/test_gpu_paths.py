@@ -89,6 +89,25 @@ def test_ckks14_paths_bit_exact(variant, oracle14, capi, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["default", "integer_transforms", "fp64_unsplit"])
+def test_ckks14_every_level_bit_exact(variant, oracle14, capi, monkeypatch):
+    """multiply + relinearise and rotate at data levels 4, 3, 2 and 1 (the cooperative tail kernel runs nl wavefronts)"""
+    o, primes, ins, want = oracle14
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    g = capi.Context(capi.CKKS, o.n, primes)
+    g.load_keys(sk=o.secret_key(), pk=o.public_key(), relin=o.relin_key(),
+                galois={e: o.galois_key(e) for e in o.galois_elts()})
+    x, y = ins["cx"], ins["cy"]
+    for level in (4, 3, 2, 1):
+        assert x.shape[1] == level
+        _same("%s mul_relin at level %d" % (variant, level), g.mul_relin(x, y), o.mul_relin(x, y))
+        _same("%s rotate at level %d" % (variant, level), g.rotate(x, 5), o.rotate(x, 5))
+        if level > 1:
+            x, y = o.mod_switch(x), o.mod_switch(y)
+    g.close()
+
+
+@pytest.mark.parametrize("variant", ["default", "integer_transforms", "fp64_unsplit"])
 def test_bfv14_keyswitch_paths_bit_exact(variant, oracle_mod, capi, monkeypatch):
     """BFVDefault(16384): 48/49-bit primes, i.e. the re-centring ('red') fp64 butterflies, coefficient-form operand"""
     for k, v in VARIANTS[variant].items():
