@@ -12,6 +12,8 @@
 // with a fast base conversion, Montgomery-reduce the q-overflow, tensor in both bases, scale by t,
 // fast floor by q into Bsk, Shenoy-Kumaresan conversion back to q.  These are element-wise over
 // coefficients (one lane = one coefficient, all limbs in registers), so they are HBM-streaming kernels.
+#include <cstdlib>
+
 #include "abc_context.hpp"
 
 namespace abc {
@@ -157,6 +159,88 @@ __global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, con
   }
 }
 
+// ---- BEHZ steps (4)-(5) for rings that fit LDS: dyadic tensor product fused into the load of the inverse transform ----
+// workgroup (ct, comp, limb): d_comp = a0 b0 | a0 b1 + a1 b0 | a1 b1 of limb `limb`, inverse transform in LDS, coefficient
+// form to d [count][3][nlm][N].  Saves the tensor kernels' round trip (7 limb transfers per limb and ciphertext).
+template <int LB, bool FP>
+__global__ __launch_bounds__((1 << LB) / 16) void k_bfv_tensor_intt(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b,
+                                                                    u64 *__restrict__ d, LimbMap map, int nlm) {
+  __shared__ u64 lds_raw[lds_words(LB)];
+  const size_t N = (size_t)1 << LB, pw = (size_t)nlm * N;
+  const int limb = blockIdx.x % nlm;
+  const int comp = (blockIdx.x / nlm) % 3;
+  const size_t ct = blockIdx.x / (3 * (size_t)nlm);
+  const int mid = map.id[limb];
+  const Mod m = mod_at(c, mid);
+  const u64 *__restrict__ a0 = a + ct * 2 * pw + (size_t)limb * N, *__restrict__ a1 = a0 + pw;
+  const u64 *__restrict__ b0 = b + ct * 2 * pw + (size_t)limb * N, *__restrict__ b1 = b0 + pw;
+  u64 *__restrict__ o = d + (ct * 3 + comp) * pw + (size_t)limb * N;
+  if constexpr (FP) {
+    double *lds = reinterpret_cast<double *>(lds_raw);
+    const FpTable t = fp_table(c, mid);
+    const double q = m.qd, qinv = m.qinv;
+    auto st = [&](int, int i, double v) { o[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, q), q, qinv); };
+    auto prod = [&](double x, double y) {  // |x|, |y| <= q  ->  |result| < q
+      const double h = x * y, l = __builtin_fma(x, y, -h);
+      return __builtin_fma(-__builtin_rint(h * qinv), q, h) + l;
+    };
+    if (comp == 0)  // workgroup-uniform: three straight-line bodies
+      ntt_inv_block_a<LB, FpArith>(lds, [&](int, int i) { return prod(fp_from_u64(a0[i]), fp_from_u64(b0[i])); }, st, t, m, 0, 0);
+    else if (comp == 2)
+      ntt_inv_block_a<LB, FpArith>(lds, [&](int, int i) { return prod(fp_from_u64(a1[i]), fp_from_u64(b1[i])); }, st, t, m, 0, 0);
+    else
+      ntt_inv_block_a<LB, FpArith>(
+          lds,
+          [&](int, int i) {  // the sum of two products is re-centred: the first inverse pass starts from |x| <= q/2
+            return fp_centre(prod(fp_from_u64(a0[i]), fp_from_u64(b1[i])) + prod(fp_from_u64(a1[i]), fp_from_u64(b0[i])), q, qinv);
+          },
+          st, t, m, 0, 0);
+  } else {
+    const NttTable t = ntt_table(c, mid);
+    auto st = [&](int, int i, u64 v) { o[i] = scale_inv_n(v, m); };
+    if (comp == 0)
+      ntt_inv_block<LB>(lds_raw, [&](int, int i) { return mul_mod(a0[i], b0[i], m); }, st, t, m, 0, 0);
+    else if (comp == 2)
+      ntt_inv_block<LB>(lds_raw, [&](int, int i) { return mul_mod(a1[i], b1[i], m); }, st, t, m, 0, 0);
+    else
+      ntt_inv_block<LB>(
+          lds_raw,
+          [&](int, int i) {
+            U128 acc = mul_wide(a0[i], b1[i]);
+            mac128(acc, a1[i], b0[i]);
+            return barrett_reduce(acc, m);
+          },
+          st, t, m, 0, 0);
+  }
+}
+
+template <int LB>
+static int launch_tensor_intt(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d, const LimbMap &map, int nlm, size_t count) {
+  bool fp = c->use_fp;
+  for (int j = 0; j < nlm; j++) fp = fp && fp_ok(c->h_mods[map.id[j]].bits);
+  const dim3 grid((unsigned)(count * 3 * nlm)), block((1 << LB) / 16);
+  if (fp)
+    hipLaunchKernelGGL((k_bfv_tensor_intt<LB, true>), grid, block, 0, c->stream, c->dc, a, b, d, map, nlm);
+  else
+    hipLaunchKernelGGL((k_bfv_tensor_intt<LB, false>), grid, block, 0, c->stream, c->dc, a, b, d, map, nlm);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+// -1: ring too large for an LDS-resident limb
+static int tensor_intt(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d, const LimbMap &map, int nlm, size_t count) {
+  if (std::getenv("ABC_HIP_NO_TENSOR_INTT")) return -1;
+  // single-ciphertext calls: the separate kernels spread a transform over many workgroups (launch_ntt, "few limbs")
+  if (c->logn == 14 && count * 3 * (size_t)nlm <= 48) return -1;
+  switch (c->logn) {
+    case 10: return launch_tensor_intt<10>(c, a, b, d, map, nlm, count);
+    case 11: return launch_tensor_intt<11>(c, a, b, d, map, nlm, count);
+    case 12: return launch_tensor_intt<12>(c, a, b, d, map, nlm, count);
+    case 13: return launch_tensor_intt<13>(c, a, b, d, map, nlm, count);
+    case 14: return launch_tensor_intt<14>(c, a, b, d, map, nlm, count);
+    default: return -1;
+  }
+}
+
 // shapes of BFVDefault(4096 / 8192 / 16384) and of config 5 get fully unrolled kernels
 #define ABC_BEHZ_DISPATCH(KERNEL, GRID, ...)                                                                          \
   do {                                                                                                                  \
@@ -180,9 +264,10 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
   const int L = c->L, nBsk = c->nBsk, nlm = L + nBsk;
   // per ciphertext pair (words): aq,bq 2*2L ; aB,bB 2*2nBsk ; dq 3L ; dB 3nBsk
   const size_t per_ct = (size_t)(4 * L + 4 * nBsk + 3 * L + 3 * nBsk) * N;
-  size_t chunk = (((size_t)1 << 30) / 8) / per_ct;
+  size_t chunk = (((size_t)4 << 30) / 8) / per_ct;  // scratch capped at 4 GiB
   if (chunk < 1) chunk = 1;
   if (chunk > count) chunk = count;
+  else if (count % chunk && count / chunk < 8) chunk = (count + count / chunk) / (count / chunk + 1);  // even chunks, no runt
   if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
   u64 *aq = (u64 *)c->ws, *bq = aq + chunk * 2 * L * N;
   u64 *aB = bq + chunk * 2 * L * N, *bB = aB + chunk * 2 * nBsk * N;
@@ -200,12 +285,21 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
     if (launch_ntt_fwd_from(c, pa, aq, qmap, L, cc * 2 * L)) return 1;  // operands stay intact: transform out of place
     if (launch_ntt_fwd_from(c, pb, bq, qmap, L, cc * 2 * L)) return 1;
     if (launch_ntt_fwd(c, aB, bmap, nBsk, cc * 4 * nBsk)) return 1;    // aB and bB are adjacent
-    hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * L * N, 256)), dim3(256), 0, c->stream, c->dc, aq, bq, dq, qmap, L, cc);
-    hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * nBsk * N, 256)), dim3(256), 0, c->stream, c->dc, aB, bB, dB, bmap, nBsk,
-                       cc);
-    ABC_HIP_CHECK(hipGetLastError());
-    if (launch_ntt_inv(c, dq, qmap, L, cc * 3 * L)) return 1;
-    if (launch_ntt_inv(c, dB, bmap, nBsk, cc * 3 * nBsk)) return 1;
+    int rq = tensor_intt(c, aq, bq, dq, qmap, L, cc);
+    if (rq > 0) return 1;
+    if (rq < 0) {
+      hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * L * N, 256)), dim3(256), 0, c->stream, c->dc, aq, bq, dq, qmap, L, cc);
+      ABC_HIP_CHECK(hipGetLastError());
+      if (launch_ntt_inv(c, dq, qmap, L, cc * 3 * L)) return 1;
+    }
+    int rb = tensor_intt(c, aB, bB, dB, bmap, nBsk, cc);
+    if (rb > 0) return 1;
+    if (rb < 0) {
+      hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * nBsk * N, 256)), dim3(256), 0, c->stream, c->dc, aB, bB, dB, bmap, nBsk,
+                         cc);
+      ABC_HIP_CHECK(hipGetLastError());
+      if (launch_ntt_inv(c, dB, bmap, nBsk, cc * 3 * nBsk)) return 1;
+    }
     launch_behz_floor(c, dq, dB, out3 + off * 3 * L * N, cc * 3);
     ABC_HIP_CHECK(hipGetLastError());
   }
