@@ -165,6 +165,8 @@ static int build_context(abc_hip_ctx *c) {
     for (int j = 0; j < l; j++) {
       k.inv_qlast[l][j] = invmod(qs[l] % qs[j], qs[j]);
       k.inv_qlast_s[l][j] = shoup(k.inv_qlast[l][j], qs[j]);
+      k.inv_qlast_c[l][j] = k.inv_qlast[l][j] > qs[j] / 2 ? -(double)(qs[j] - k.inv_qlast[l][j]) : (double)k.inv_qlast[l][j];
+      k.inv_qlast_cq[l][j] = k.inv_qlast_c[l][j] / (double)qs[j];
     }
 
   std::vector<uint32_t> slot_map;

@@ -25,7 +25,8 @@ struct DevConst {
   u64 inv_special[kMaxLimbs], inv_special_s[kMaxLimbs];        // q_special^-1 mod q_j (+Shoup)
   u64 inv_qlast[kMaxLimbs][kMaxLimbs], inv_qlast_s[kMaxLimbs][kMaxLimbs];  // [l][j] = q_l^-1 mod q_j
   u64 special_mod_q[kMaxLimbs];
-  double inv_special_c[kMaxLimbs], inv_special_cq[kMaxLimbs];  // fp64 path: centred value and value / q_j                                // q_special mod q_j (key generation)
+  double inv_special_c[kMaxLimbs], inv_special_cq[kMaxLimbs];  // fp64 path: centred value and value / q_j
+  double inv_qlast_c[kMaxLimbs][kMaxLimbs], inv_qlast_cq[kMaxLimbs][kMaxLimbs];  // same for inv_qlast (rescale)                                // q_special mod q_j (key generation)
   // BFV plaintext scaling (Evaluator::add_plain / Encryptor)
   u64 q_mod_t, upper_half_threshold, t;
   u64 coeff_div_plain[kMaxLimbs], upper_half_increment[kMaxLimbs];

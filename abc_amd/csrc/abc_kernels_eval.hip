@@ -7,6 +7,8 @@
 // Key switching follows seal::Evaluator::switch_key_inplace: decomposition limb J is reduced modulo
 // every key-level prime, transformed, multiplied with key[J] and accumulated; the special-prime limb is
 // then divided out with rounding.  All outputs are fully reduced, hence bit-comparable with oracle/.
+#include <cstdlib>
+
 #include "abc_context.hpp"
 
 namespace abc {
@@ -298,10 +300,78 @@ __global__ __launch_bounds__(256) void k_rescale_finish(DevCtx c, const u64 *in,
   }
 }
 
+// ---- the same for rings that fit LDS and primes below 2^50: two kernels instead of five ----
+// R1 (poly): inverse transform of the last limb, read in place, + q_last/2 -> scratch.
+// R2 (poly, j < nl-1): scratch + rounding fix as operand of a forward transform modulo q_j in LDS (no reduction: the
+//     fp64 bound absorbs a 50-bit operand), then (in_j - transform) * q_last^-1 -> out_j.  The nl-1 workgroups that read one
+//     scratch polynomial are 8 apart in blockIdx (one XCD, one L2).  7 + 2 limb transfers per polynomial instead of 23.
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_rescale_intt_fp(DevCtx c, const u64 *__restrict__ in, u64 *__restrict__ last,
+                                                                    int nl) {
+  __shared__ double lds[lds_words(LB)];
+  const size_t N = (size_t)1 << LB;
+  const Mod m = mod_at(c, nl - 1);
+  const FpTable t = fp_table(c, nl - 1);
+  const double half = (double)(m.q >> 1);
+  const u64 *__restrict__ src = in + ((size_t)blockIdx.x * nl + (nl - 1)) * N;
+  u64 *__restrict__ dst = last + (size_t)blockIdx.x * N;
+  ntt_inv_block_a<LB, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(src[i]); },
+      [&](int, int i, double v) { dst[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd) + half, m.qd, m.qinv); }, t, m, 0,
+      0);
+}
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_rescale_ntt_fp(DevCtx c, const u64 *__restrict__ in, const u64 *__restrict__ last,
+                                                                   u64 *__restrict__ out, int nl, int npoly) {
+  __shared__ double lds[lds_words(LB)];
+  const int nlo = nl - 1;
+  const unsigned per = 8u * (unsigned)nlo;
+  const unsigned grp = blockIdx.x / per, rem = blockIdx.x % per;
+  const unsigned left = (unsigned)npoly - grp * 8u, gsz = left < 8u ? left : 8u;  // the last group may be ragged
+  const int j = (int)(rem / gsz);
+  const size_t p = (size_t)grp * 8 + rem % gsz;
+  const size_t N = (size_t)1 << LB;
+  const Mod m = mod_at(c, j);
+  const FpTable t = fp_table(c, j);
+  const u64 half = c.mods[nl - 1].q >> 1;
+  const u64 hm = reduce64(half, m);
+  const double fix = hm ? (double)(m.q - hm) : 0.0;
+  const double inv = c.cst->inv_qlast_c[nl - 1][j], inv_q = c.cst->inv_qlast_cq[nl - 1][j];
+  const u64 *__restrict__ src = last + p * N;
+  const u64 *__restrict__ x = in + (p * nl + j) * N;
+  u64 *__restrict__ o = out + (p * nlo + j) * N;
+  ntt_fwd_block_a<LB, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(src[i]) + fix; },
+      [&](int, int i, double v) { o[i] = fp_to_canon(fp_mul_lazy(fp_from_u64(x[i]) - v, inv, inv_q, m.qd), m.qd, m.qinv); }, t, m, 0,
+      0);
+}
+template <int LB>
+static int launch_rescale_fp(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, size_t polys) {
+  const size_t N = (size_t)1 << LB;
+  if (ensure_workspace(c, polys * N * 8)) return 1;
+  u64 *last = (u64 *)c->ws;
+  const dim3 block((1 << LB) / 16);
+  hipLaunchKernelGGL(k_rescale_intt_fp<LB>, dim3((unsigned)polys), block, 0, c->stream, c->dc, in, last, nl);
+  hipLaunchKernelGGL(k_rescale_ntt_fp<LB>, dim3((unsigned)(polys * (nl - 1))), block, 0, c->stream, c->dc, in, last, out, nl,
+                     (int)polys);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_rescale(abc_hip_ctx *c, const u64 *in, u64 *out, int size, int nl, size_t count) {
   if (nl < 2) { set_error("rescale: no limb left to drop"); return 1; }
   const size_t N = (size_t)c->n, polys = count * size;
   if (!polys) return 0;
+  bool fp = c->use_fp && c->logn <= 14 && in != out && !std::getenv("ABC_HIP_NO_FUSED");
+  for (int j = 0; j < nl; j++) fp = fp && fp_ok(c->h_mods[j].bits);
+  if (fp) switch (c->logn) {
+      case 10: return launch_rescale_fp<10>(c, in, out, nl, polys);
+      case 11: return launch_rescale_fp<11>(c, in, out, nl, polys);
+      case 12: return launch_rescale_fp<12>(c, in, out, nl, polys);
+      case 13: return launch_rescale_fp<13>(c, in, out, nl, polys);
+      case 14: return launch_rescale_fp<14>(c, in, out, nl, polys);
+      default: break;
+    }
   if (ensure_workspace(c, (polys * N + polys * (nl - 1) * N) * 8)) return 1;
   u64 *last = (u64 *)c->ws, *tmod = last + polys * N;
   hipLaunchKernelGGL(k_gather_last, dim3(grid_for(polys * N, 256)), dim3(256), 0, c->stream, c->dc, in, last, nl, polys);

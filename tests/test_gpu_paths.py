@@ -103,6 +103,10 @@ def test_ckks14_every_level_bit_exact(variant, oracle14, capi, monkeypatch):
         _same("%s mul_relin at level %d" % (variant, level), g.mul_relin(x, y), o.mul_relin(x, y))
         _same("%s rotate at level %d" % (variant, level), g.rotate(x, 5), o.rotate(x, 5))
         if level > 1:
+            _same("%s rescale at level %d" % (variant, level), g.rescale(x), o.rescale(x))
+            both = np.stack([x, y, x])  # batched, odd count: exercises the ragged XCD group
+            _same("%s batched rescale at level %d" % (variant, level), g.rescale(both)[1], o.rescale(y))
+        if level > 1:
             x, y = o.mod_switch(x), o.mod_switch(y)
     g.close()
 
