@@ -740,12 +740,14 @@ int abc_hip_rescale(abc_hip_ctx *c, const uint64_t *in, uint64_t *out, int size,
   CTX_GUARD(c);
   if (c->scheme != ABC_HIP_SCHEME_CKKS) { set_error("rescale is a CKKS operation"); return 1; }
   if (check_level(c, nl)) return 1;
+  if (in == out) { set_error("rescale: d_out must not alias d_in (the output has one limb less per polynomial)"); return 1; }
   return launch_rescale(c, in, out, size, nl, count);
 }
 int abc_hip_mod_switch(abc_hip_ctx *c, const uint64_t *in, uint64_t *out, int size, int nl, size_t count) {
   CTX_GUARD(c);
   if (c->scheme != ABC_HIP_SCHEME_CKKS) { set_error("mod_switch is only implemented for CKKS"); return 1; }
   if (check_level(c, nl)) return 1;
+  if (in == out) { set_error("mod_switch: d_out must not alias d_in (the output has one limb less per polynomial)"); return 1; }
   return launch_drop_last(c, in, out, size, nl, count);
 }
 

@@ -114,7 +114,8 @@ int abc_hip_add_plain(abc_hip_ctx *ctx, const uint64_t *d_ct, const uint64_t *d_
 /* Evaluator::sub_plain(_inplace) (:145,:184) */
 int abc_hip_sub_plain(abc_hip_ctx *ctx, const uint64_t *d_ct, const uint64_t *d_plain, size_t plain_stride, uint64_t *d_out,
                       int size, int nl, size_t count);
-/* CKKS only: Evaluator::rescale_to_next / mod_switch_to_next (no reference call site) */
+/* CKKS only: Evaluator::rescale_to_next / mod_switch_to_next (no reference call site).
+ * d_in [count][size][nl][N] -> d_out [count][size][nl-1][N]; d_out must not alias d_in (error otherwise). */
 int abc_hip_rescale(abc_hip_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int size, int nl, size_t count);
 int abc_hip_mod_switch(abc_hip_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, int size, int nl, size_t count);
 
