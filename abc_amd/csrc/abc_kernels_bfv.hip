@@ -330,6 +330,48 @@ __global__ __launch_bounds__(256) void k_mul_plain_ntt(DevCtx c, u64 *ct, const 
   }
 }
 
+// multiply_plain for rings that fit LDS and primes below 2^50, one kernel per ciphertext limb: forward transform in LDS,
+// dyadic product with the plaintext's NTT form in registers (the forward transform's last pass leaves each lane exactly the
+// words the inverse transform's first pass wants), inverse transform in LDS.  3 limb transfers instead of 9.
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_bfv_mul_plain_fused_fp(DevCtx c, const u64 *__restrict__ ct,
+                                                                           const u64 *__restrict__ lifted, size_t lifted_stride,
+                                                                           u64 *__restrict__ out, int size) {
+  __shared__ double lds[lds_words(LB)];
+  const size_t N = (size_t)1 << LB;
+  const int L = c.L;
+  const int limb = blockIdx.x % L;
+  const size_t poly = blockIdx.x / L;  // ct * size + comp
+  const size_t ci = poly / size;
+  const Mod m = mod_at(c, limb);
+  const FpTable t = fp_table(c, limb);
+  const double q = m.qd, qinv = m.qinv;
+  const u64 *__restrict__ src = ct + (poly * L + limb) * N;
+  const u64 *__restrict__ pl = lifted + ci * lifted_stride + (size_t)limb * N;
+  u64 *__restrict__ dst = out + (poly * L + limb) * N;
+  double y[16];
+  ntt_fwd_block_a<LB, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(src[i]); },
+      [&](int r, int i, double v) {
+        const double w = fp_from_u64(pl[i]);
+        const double h = v * w, l = __builtin_fma(v, w, -h);
+        y[r] = fp_centre(__builtin_fma(-__builtin_rint(h * qinv), q, h) + l, q, qinv);
+      },
+      t, m, 0, 0);
+  block_sync_lds();  // the forward transform's last pass has read its LDS words
+  ntt_inv_block_a<LB, FpArith>(
+      lds, [&](int r, int) { return y[r]; },
+      [&](int, int i, double v) { dst[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, q), q, qinv); }, t, m, 0, 0);
+}
+template <int LB>
+static int launch_mul_plain_fused(abc_hip_ctx *c, const u64 *ct, const u64 *lifted, size_t lifted_stride, u64 *out, int size,
+                                  size_t count) {
+  hipLaunchKernelGGL(k_bfv_mul_plain_fused_fp<LB>, dim3((unsigned)(count * size * c->L)), dim3((1 << LB) / 16), 0, c->stream, c->dc,
+                     ct, lifted, lifted_stride, out, size);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int bfv_multiply_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t plain_stride, u64 *out, int size, size_t count) {
   if (!count) return 0;
   const size_t N = (size_t)c->n;
@@ -342,6 +384,19 @@ int bfv_multiply_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t p
   hipLaunchKernelGGL(k_plain_lift, dim3(grid_for(nplain * N, 256)), dim3(256), 0, c->stream, c->dc, plain, lifted, nplain);
   ABC_HIP_CHECK(hipGetLastError());
   if (launch_ntt_fwd(c, lifted, qmap, L, nplain * L)) return 1;
+  bool fp = c->use_fp && c->logn <= 14 && !std::getenv("ABC_HIP_NO_FUSED");
+  for (int j = 0; j < L; j++) fp = fp && fp_ok(c->h_mods[j].bits);
+  if (fp && (c->logn < 14 || count * size * L > 48)) {  // single-ciphertext calls keep the spread-out transforms
+    const size_t ls = plain_stride ? (size_t)L * N : 0;
+    switch (c->logn) {
+      case 10: return launch_mul_plain_fused<10>(c, ct, lifted, ls, out, size, count);
+      case 11: return launch_mul_plain_fused<11>(c, ct, lifted, ls, out, size, count);
+      case 12: return launch_mul_plain_fused<12>(c, ct, lifted, ls, out, size, count);
+      case 13: return launch_mul_plain_fused<13>(c, ct, lifted, ls, out, size, count);
+      case 14: return launch_mul_plain_fused<14>(c, ct, lifted, ls, out, size, count);
+      default: break;
+    }
+  }
   if (out != ct) ABC_HIP_CHECK(hipMemcpyAsync(out, ct, count * size * L * N * 8, hipMemcpyDeviceToDevice, c->stream));
   if (launch_ntt_fwd(c, out, qmap, L, count * size * L)) return 1;
   hipLaunchKernelGGL(k_mul_plain_ntt, dim3(grid_for(count * size * L * N, 256)), dim3(256), 0, c->stream, c->dc, out, lifted,

@@ -127,4 +127,11 @@ def test_bfv14_keyswitch_paths_bit_exact(variant, oracle_mod, capi, monkeypatch)
     _same(variant + " bfv rotate extreme", g.rotate(ex, 1), o.rotate(ex, 1))
     ct = o.encrypt(o.encode(oracle_mod.expand_vector([3, 1, 4, 1, 5], o.n)), 9)
     _same(variant + " bfv mul_relin", g.mul_relin(ct, ct), o.mul_relin(ct, ct))
+    # multiply_plain: one call (spread-out transforms) and a batch of four (fused forward / product / inverse kernel)
+    pl = o.encode(oracle_mod.expand_vector([7, 0, 2, 5], o.n))
+    _same(variant + " bfv multiply_plain", g.multiply_plain(ct, pl), o.multiply_plain(ct, pl))
+    batch = np.stack([ct, ex, ct, ex])
+    got = g.multiply_plain(batch, pl)
+    _same(variant + " bfv multiply_plain batch[1]", got[1], o.multiply_plain(ex, pl))
+    _same(variant + " bfv multiply_plain batch[2]", got[2], o.multiply_plain(ct, pl))
     g.close()

@@ -57,10 +57,12 @@ def main():
         b, _ = rand_ct(g, rng, B, 2, L)
         out = g.alloc(nb)
         cb = C.c_size_t(B)
+        plain = g.upload(rng.integers(0, g.t, size=n, dtype=np.uint64))
         ops = {
             "bfv%d_mul_relin" % n: lambda: g.op("mul_relin", a.ptr, b.ptr, out.ptr, L, cb),
             "bfv%d_rotate_1" % n: lambda: g.op("rotate", a.ptr, out.ptr, L, 1, cb),
             "bfv%d_add" % n: lambda: g.op("add", a.ptr, b.ptr, out.ptr, 2, L, cb),
+            "bfv%d_multiply_plain" % n: lambda: g.op("multiply_plain", a.ptr, plain.ptr, C.c_size_t(0), out.ptr, 2, L, cb),
         }
         for k, fn in ops.items():
             ms = timeit(g, fn)
