@@ -322,6 +322,10 @@ static int apply_galois(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, uint32_
   if (!count) return 0;
   const size_t N = (size_t)c->n, pw = (size_t)nl * N;
   const bool ntt_form = (c->scheme == ABC_HIP_SCHEME_CKKS);
+  {  // N = 2^14 CKKS: the permutation is a block-local gather, done inside the key-switch kernels
+    const int rc = rotate_fused(c, in, elt, it->second, out, nl, count);
+    if (rc >= 0) return rc;
+  }
   // g(c0), g(c1) live in arena 0 (keyswitch_generic uses c->ws)
   if (ensure_aux(c, 0, count * 2 * pw * 8)) return 1;
   u64 *g = (u64 *)c->aux[0];

@@ -182,6 +182,7 @@ int keygen(abc_hip_ctx *c, uint64_t seed);
 int microbench(abc_hip_ctx *c, int which, int iters, double *ms);
 
 // LDS-resident fast paths (N <= 2^14); return -1 if not applicable (caller falls back to the generic kernels)
+int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *out, int nl, size_t count);
 int keyswitch_fused(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out2, int nl, size_t count,
                     const u64 *addend, size_t addend_stride, bool add_c1);
 int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count);

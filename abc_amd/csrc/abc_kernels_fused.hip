@@ -397,7 +397,7 @@ template <int LB>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_fp(DevCtx c, const u64 *__restrict__ ksacc,
                                                                         const u64 *__restrict__ tlast, const u64 *__restrict__ addend,
                                                                         size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl,
-                                                                        int ncc) {
+                                                                        int ncc, u32 gelt) {
   __shared__ double lds[lds_words(LB)];
   // The nl workgroups that read the same special-prime polynomial (ct, comp) are 8 apart in blockIdx: workgroups go
   // round-robin over the 8 XCDs, so they share one L2 and the polynomial is fetched from HBM once, not nl times.
@@ -425,7 +425,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_fp(DevCtx c
         lds, ld,
         [&](int, int i, double v) {
           const double d = fp_from_u64(ks[i]) - v;
-          o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd) + fp_from_u64(cin[i]), m.qd, m.qinv);
+          o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd) + fp_from_u64(cin[galois_ntt_src((u32)i, gelt, LB)]), m.qd, m.qinv);
         },
         t, m, 0, 0);
   } else {
@@ -574,7 +574,8 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_pass0_fp(DevCtx
 // prime including q_j itself.
 template <int LB, bool CKKS>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCtx c, const u64 *__restrict__ src, size_t src_stride,
-                                                                           double *__restrict__ part, int nl, int per_target) {
+                                                                           double *__restrict__ part, int nl, int per_target,
+                                                                           u32 gelt) {
   static_assert(LB == 14, "split transforms are laid out for N = 2^14");
   __shared__ double lds[CKKS ? lds_words(LB) : 1];
   const size_t N = (size_t)1 << LB;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCt
     const Mod m = mod_at(c, j);
     const FpTable t = fp_table(c, j);
     ntt_inv_block_a<LB, FpArith>(
-        lds, [&](int, int i) { return fp_from_u64(sp[i]); },
+        lds, [&](int, int i) { return fp_from_u64(sp[galois_ntt_src((u32)i, gelt, LB)]); },  // gelt: rotation folded in
         [&](int r, int, double v) {
           double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
           x[r] = w < 0.0 ? w + m.qd : w;
@@ -623,7 +624,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCt
 // J = I, CKKS: the operand's own NTT form), acc_c += x_J * key[J][c][I]; canonical sums to ksacc / tsp.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_fused_tailmac_fp(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ ntt,
                                                          size_t ntt_stride, const u64 *__restrict__ key, u64 *__restrict__ ksacc,
-                                                         u64 *__restrict__ tsp, int nl) {
+                                                         u64 *__restrict__ tsp, int nl, u32 gelt) {
   __shared__ double lds[lds_words(10)];
   const int blk = blockIdx.x & 15;
   const int I = (blockIdx.x >> 4) % (nl + 1);
@@ -645,13 +646,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
       acc1[r] += fp_mulmod(v, fp_from_u64(k1[i]), q, qinv);
     };
     if (ntt && J == I) {
-      const u64 *__restrict__ xs = ntt + ct * ntt_stride + (size_t)J * N + ((size_t)blk << 10);
+      const u64 *__restrict__ xl = ntt + ct * ntt_stride + (size_t)J * N;  // whole limb: a rotation gathers across blocks
 #pragma unroll
       for (int g = 0; g < 4; g++)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int i = 4 * (tid + 64 * g) + k;
-          accum(4 * g + k, i, fp_from_u64(xs[i]));
+          accum(4 * g + k, i, fp_from_u64(xl[galois_ntt_src((u32)((blk << 10) + i), gelt, c.logn)]));
         }
     } else {
       const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
 __global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const double *__restrict__ part,
                                                                 const u64 *__restrict__ ntt, size_t ntt_stride,
                                                                 const u64 *__restrict__ key, u64 *__restrict__ ksacc,
-                                                                u64 *__restrict__ tsp, int nl) {
+                                                                u64 *__restrict__ tsp, int nl, u32 gelt) {
   extern __shared__ double dyn[];
   double *acc = dyn;  // [2][4][256]: component, k, p  (element 4p + k of the block): lanes walk p, conflict-free
   const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -706,13 +707,13 @@ __global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const 
       __hip_atomic_fetch_add(acc + 1024 + slot, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     if (ntt && J == I) {
-      const u64 *__restrict__ xs = ntt + ct * ntt_stride + (size_t)J * N + ((size_t)blk << 10);
+      const u64 *__restrict__ xl = ntt + ct * ntt_stride + (size_t)J * N;  // whole limb: a rotation gathers across blocks
 #pragma unroll
       for (int g = 0; g < 4; g++)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int i = 4 * (lane + 64 * g) + k;
-          accum(4 * g + k, i, fp_from_u64(xs[i]));
+          accum(4 * g + k, i, fp_from_u64(xl[galois_ntt_src((u32)((blk << 10) + i), gelt, c.logn)]));
         }
     } else {
       const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
@@ -769,7 +770,8 @@ static inline bool needs_guard(const abc_hip_ctx *c) {  // unguarded butterflies
 template <int LB>
 static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s, const u64 *coef, size_t coef_stride, const u64 *ntt,
                            size_t ntt_stride, const u64 *key, const u64 *addend, size_t addend_stride, bool add_c1, u64 *out, int nl,
-                           size_t cc, int dec_ready = 0 /* 1: dec holds finished limbs, 2: half-done limbs (split) */) {
+                           size_t cc, int dec_ready = 0 /* 1: dec holds finished limbs, 2: half-done limbs (split) */,
+                           u32 gelt = 0 /* split CKKS path: Galois element folded into the operand / addend reads */) {
   const size_t N = (size_t)1 << LB;
   const dim3 block((1 << LB) / 16);
   const bool ckks = (c->scheme == 2);
@@ -783,17 +785,17 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
     if (dec_ready == 2 && nl <= 12 && !std::getenv("ABC_HIP_TAILMAC_SERIAL"))
       hipLaunchKernelGGL(k_fused_tailmac_coop_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64 * nl),
                          (size_t)(2048 + nl * lds_words(10)) * 8, st, c->dc, (const double *)s.dec,
-                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl);
+                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, gelt);
     else if (dec_ready == 2)
       hipLaunchKernelGGL(k_fused_tailmac_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64), 0, st, c->dc, (const double *)s.dec,
-                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl);
+                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, gelt);
     else
       hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
                          ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
     hipLaunchKernelGGL(k_fused_ks_special_intt_fp<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, s.tsp, s.tlast);
     if (ckks)
       hipLaunchKernelGGL(k_fused_ks_moddown_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
-                         add_c1 ? 1 : 0, out, nl, (int)(cc * 2));
+                         add_c1 ? 1 : 0, out, nl, (int)(cc * 2), gelt);
     else
       hipLaunchKernelGGL(k_fused_ks_moddown_bfv_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
                          add_c1 ? 1 : 0, out, nl);
@@ -940,7 +942,7 @@ int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
 // target: [nl][N] per ciphertext at target + ct*target_stride, in the ciphertext's own form (BFV coefficient, CKKS NTT)
 template <int LB>
 static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count,
-                         const u64 *addend, size_t addend_stride, bool add_c1) {
+                         const u64 *addend, size_t addend_stride, bool add_c1, u32 gelt = 0) {
   const size_t N = (size_t)1 << LB;
   const bool ckks = (c->scheme == 2);
   const ChunkPlan p = plan_chunks(c, nl, count);
@@ -961,13 +963,13 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
       split = all_fp(c) && !std::getenv("ABC_HIP_NO_SPLIT");
       if (split && ckks)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, true>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
-                           target_stride, (double *)s.dec, nl, 0);
+                           target_stride, (double *)s.dec, nl, 0, gelt);
       else if (split && cc * nl < 128)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false>), dim3((unsigned)(cc * nl * (nl + 1))), dim3((1 << LB) / 16), 0, st,
-                           c->dc, tg, target_stride, (double *)s.dec, nl, 1);
+                           c->dc, tg, target_stride, (double *)s.dec, nl, 1, 0u);
       else if (split)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
-                           target_stride, (double *)s.dec, nl, 0);
+                           target_stride, (double *)s.dec, nl, 0, 0u);
     }
     if (split) {
     } else if (ckks) {  // operand arrives in NTT form: coefficient form via one in-LDS inverse transform per limb
@@ -981,10 +983,20 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
       coef_stride = (size_t)nl * N;
     }
     if (keyswitch_stage<LB>(c, st, s, coef, coef_stride, tg, target_stride, key, addend ? addend + off * addend_stride : nullptr,
-                            addend_stride, add_c1, out + off * 2 * nl * N, nl, cc, split ? 2 : 0))
+                            addend_stride, add_c1, out + off * 2 * nl * N, nl, cc, split ? 2 : 0, gelt))
       return 1;
   }
   return join_lanes(c, p.lanes);
+}
+
+// CKKS rotation with the Galois permutation folded into the key switch (N = 2^14, fp64 split path): in [count][2][nl][N]
+// NTT form; out = (g(c0) + ks0, ks1), ks = KeySwitch(g(c1)).  -1: not applicable, caller permutes first.
+int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *out, int nl, size_t count) {
+  if (c->logn != 14 || c->scheme != 2 || !all_fp(c) || in == out) return -1;
+  if (std::getenv("ABC_HIP_NO_SPLIT") || std::getenv("ABC_HIP_NO_FUSED") || std::getenv("ABC_HIP_NO_GALOIS_FUSION")) return -1;
+  if (!count) return 0;
+  const size_t N = (size_t)c->n, pw = (size_t)nl * N;
+  return run_keyswitch<14>(c, in + pw, 2 * pw, key, out, nl, count, in, 2 * pw, false, elt);
 }
 
 int keyswitch_fused(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count,
