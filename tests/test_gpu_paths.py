@@ -135,3 +135,36 @@ def test_bfv14_keyswitch_paths_bit_exact(variant, oracle_mod, capi, monkeypatch)
     _same(variant + " bfv multiply_plain batch[1]", got[1], o.multiply_plain(ex, pl))
     _same(variant + " bfv multiply_plain batch[2]", got[2], o.multiply_plain(ct, pl))
     g.close()
+
+
+def test_fp64_and_integer_paths_agree_on_random_residues(oracle14, capi, monkeypatch):
+    """2 000 random ciphertext pairs (uniform residues, plus rows forced to the ends of [0, q)): the fp64 kernels and the
+    integer kernels must agree word for word -- a rounding slip in the fp64 quotient estimate that left the exact range
+    would show up here long before it showed up in a decrypted slot."""
+    o, primes, _, _ = oracle14
+    keys = dict(sk=o.secret_key(), pk=o.public_key(), relin=o.relin_key(),
+                galois={e: o.galois_key(e) for e in o.galois_elts()})
+    g_fp = capi.Context(capi.CKKS, o.n, primes)
+    g_fp.load_keys(**keys)
+    monkeypatch.setenv("ABC_HIP_NO_FP64", "1")
+    g_int = capi.Context(capi.CKKS, o.n, primes)
+    g_int.load_keys(**keys)
+    monkeypatch.delenv("ABC_HIP_NO_FP64")
+    rng = np.random.default_rng(99)
+    B = 200
+    for rnd in range(10):
+        nl = int(rng.integers(1, 5))
+        a = np.stack([rng.integers(0, q, size=(B, 2, o.n), dtype=np.uint64) for q in primes[:nl]], axis=2)
+        b = np.stack([rng.integers(0, q, size=(B, 2, o.n), dtype=np.uint64) for q in primes[:nl]], axis=2)
+        for j in range(nl):  # a few adversarial rows per batch
+            a[0, :, j, :] = primes[j] - 1
+            b[0, :, j, :] = primes[j] - 1
+            a[1, :, j, ::2] = 0
+            b[1, :, j, 1::2] = (primes[j] - 1) // 2
+        _same("round %d mul_relin nl=%d" % (rnd, nl), g_fp.mul_relin(a, b), g_int.mul_relin(a, b))
+        steps = int(rng.integers(1, o.n // 2))
+        _same("round %d rotate %d nl=%d" % (rnd, steps, nl), g_fp.rotate(a, steps), g_int.rotate(a, steps))
+        if nl > 1:
+            _same("round %d rescale nl=%d" % (rnd, nl), g_fp.rescale(a), g_int.rescale(a))
+    g_fp.close()
+    g_int.close()
