@@ -682,10 +682,13 @@ __global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const 
                                                                 const u64 *__restrict__ key, u64 *__restrict__ ksacc,
                                                                 u64 *__restrict__ tsp, int nl, u32 gelt) {
   extern __shared__ double dyn[];
-  double *acc = dyn;  // [2][4][256]: component, k, p  (element 4p + k of the block): lanes walk p, conflict-free
+  // LDS: max(nl, 2) transform buffers of 8.5 KiB; once every wavefront's transform is done the first two double as the
+  // two accumulators ([4][256]: k, p for element 4p + k of the block: lanes walk p, conflict-free), so four workgroups
+  // (16 wavefronts) fit a CU
   const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  double *lds = dyn + 2048 + J * lds_words(10);
+  double *lds = dyn + J * lds_words(10);
+  double *acc0 = dyn, *acc1 = dyn + lds_words(10);
   const int blk = blockIdx.x & 15;
   const int I = (blockIdx.x >> 4) % (nl + 1);
   const size_t ct = (blockIdx.x >> 4) / (nl + 1);
@@ -694,31 +697,39 @@ __global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const 
   const Mod m = mod_at(c, ki);
   const FpTable t = fp_table(c, ki);
   const double q = m.qd, qinv = m.qinv;
-  for (int i = threadIdx.x; i < 2048; i += blockDim.x) acc[i] = 0.0;
+  double x[16];  // this wavefront's limb on the block, final transform layout: slot 4g + k = element 4 (lane + 64 g) + k
+  if (ntt && J == I) {
+    const u64 *__restrict__ xl = ntt + ct * ntt_stride + (size_t)J * N;  // whole limb: a rotation gathers across blocks
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        x[4 * g + k] = fp_from_u64(xl[galois_ntt_src((u32)((blk << 10) + 4 * (lane + 64 * g) + k), gelt, c.logn)]);
+  } else {
+    const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
+    ntt_fwd_block_a<10, FpArith>(
+        lds, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int r, int, double v) { x[r] = v; }, t, m, 4, blk, lane);
+  }
+  __syncthreads();  // every transform has left LDS
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) acc0[i] = acc1[i] = 0.0;
   __syncthreads();
   {
     const u64 *__restrict__ k0 = key + (((size_t)J * 2 + 0) * c.K + ki) * N + ((size_t)blk << 10);
     const u64 *__restrict__ k1 = key + (((size_t)J * 2 + 1) * c.K + ki) * N + ((size_t)blk << 10);
-    auto accum = [&](int, int i, double v) {
-      const int slot = ((i & 3) << 8) + (i >> 2);
-      const double p0 = fp_mulmod(v, fp_from_u64(k0[i]), q, qinv);
-      const double p1 = fp_mulmod(v, fp_from_u64(k1[i]), q, qinv);
-      __hip_atomic_fetch_add(acc + slot, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(acc + 1024 + slot, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    if (ntt && J == I) {
-      const u64 *__restrict__ xl = ntt + ct * ntt_stride + (size_t)J * N;  // whole limb: a rotation gathers across blocks
 #pragma unroll
-      for (int g = 0; g < 4; g++)
+    for (int g = 0; g < 4; g++) {
+      const int p = lane + 64 * g;
+      const u64x2 a0 = reinterpret_cast<const u64x2 *>(k0 + 4 * p)[0], a1 = reinterpret_cast<const u64x2 *>(k0 + 4 * p)[1];
+      const u64x2 b0 = reinterpret_cast<const u64x2 *>(k1 + 4 * p)[0], b1 = reinterpret_cast<const u64x2 *>(k1 + 4 * p)[1];
+      const u64 kk0[4] = {a0.x, a0.y, a1.x, a1.y}, kk1[4] = {b0.x, b0.y, b1.x, b1.y};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int i = 4 * (lane + 64 * g) + k;
-          accum(4 * g + k, i, fp_from_u64(xl[galois_ntt_src((u32)((blk << 10) + i), gelt, c.logn)]));
-        }
-    } else {
-      const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
-      ntt_fwd_block_a<10, FpArith>(
-          lds, [&](int, int i) { return fp_centre(src[i], q, qinv); }, accum, t, m, 4, blk, lane);
+      for (int k = 0; k < 4; k++) {
+        const int slot = (k << 8) + p;
+        __hip_atomic_fetch_add(acc0 + slot, fp_mulmod(x[4 * g + k], fp_from_u64(kk0[k]), q, qinv), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(acc1 + slot, fp_mulmod(x[4 * g + k], fp_from_u64(kk1[k]), q, qinv), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
   }
   __syncthreads();
@@ -726,13 +737,13 @@ __global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const 
   u64 *__restrict__ o1 = ((I == nl) ? tsp + (ct * 2 + 1) * N : ksacc + ((ct * 2 + 1) * nl + I) * N) + ((size_t)blk << 10);
   for (int p = threadIdx.x; p < 256; p += blockDim.x) {
     u64x2 r;
-    r.x = fp_to_canon(acc[p], q, qinv); r.y = fp_to_canon(acc[256 + p], q, qinv);
+    r.x = fp_to_canon(acc0[p], q, qinv); r.y = fp_to_canon(acc0[256 + p], q, qinv);
     *reinterpret_cast<u64x2 *>(o0 + 4 * p) = r;
-    r.x = fp_to_canon(acc[512 + p], q, qinv); r.y = fp_to_canon(acc[768 + p], q, qinv);
+    r.x = fp_to_canon(acc0[512 + p], q, qinv); r.y = fp_to_canon(acc0[768 + p], q, qinv);
     *reinterpret_cast<u64x2 *>(o0 + 4 * p + 2) = r;
-    r.x = fp_to_canon(acc[1024 + p], q, qinv); r.y = fp_to_canon(acc[1280 + p], q, qinv);
+    r.x = fp_to_canon(acc1[p], q, qinv); r.y = fp_to_canon(acc1[256 + p], q, qinv);
     *reinterpret_cast<u64x2 *>(o1 + 4 * p) = r;
-    r.x = fp_to_canon(acc[1536 + p], q, qinv); r.y = fp_to_canon(acc[1792 + p], q, qinv);
+    r.x = fp_to_canon(acc1[512 + p], q, qinv); r.y = fp_to_canon(acc1[768 + p], q, qinv);
     *reinterpret_cast<u64x2 *>(o1 + 4 * p + 2) = r;
   }
 }
@@ -781,10 +792,10 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
   if (all_fp(c)) {
     if (!dec_ready)
       hipLaunchKernelGGL(k_fused_ks_decomp_ntt_fp<LB>, dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
-    // cooperative form: nl wavefronts and 16 + 8.5 nl KiB of LDS per workgroup
+    // cooperative form: nl wavefronts and 8.5 max(nl, 2) KiB of LDS per workgroup
     if (dec_ready == 2 && nl <= 12 && !std::getenv("ABC_HIP_TAILMAC_SERIAL"))
       hipLaunchKernelGGL(k_fused_tailmac_coop_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64 * nl),
-                         (size_t)(2048 + nl * lds_words(10)) * 8, st, c->dc, (const double *)s.dec,
+                         (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8, st, c->dc, (const double *)s.dec,
                          ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, gelt);
     else if (dec_ready == 2)
       hipLaunchKernelGGL(k_fused_tailmac_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64), 0, st, c->dc, (const double *)s.dec,
