@@ -393,7 +393,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_special_intt_fp(Dev
 // K3, CKKS.  The special-prime polynomial (< q_sp <= 2^50) plus the rounding fix enters the transform unreduced
 // (see K2a); the subtraction, the scaling by q_sp^-1 and the addend stay in doubles until the single
 // canonicalisation of the store.
-template <int LB>
+template <int LB, bool GAL>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_fp(DevCtx c, const u64 *__restrict__ ksacc,
                                                                         const u64 *__restrict__ tlast, const u64 *__restrict__ addend,
                                                                         size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl,
@@ -425,7 +425,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_fp(DevCtx c
         lds, ld,
         [&](int, int i, double v) {
           const double d = fp_from_u64(ks[i]) - v;
-          o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd) + fp_from_u64(cin[galois_ntt_src((u32)i, gelt, LB)]), m.qd, m.qinv);
+          o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd) + fp_from_u64(cin[galois_ntt_src<GAL>((u32)i, gelt, LB)]), m.qd, m.qinv);
         },
         t, m, 0, 0);
   } else {
@@ -572,7 +572,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_pass0_fp(DevCtx
 // K1s for a general key switch.  CKKS (the operand arrives in NTT form): inverse transform of limb j in LDS, then the
 // register pass modulo every other key prime.  BFV (coefficient form): no LDS at all, the register pass modulo every key
 // prime including q_j itself.
-template <int LB, bool CKKS>
+template <int LB, bool CKKS, bool GAL>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCtx c, const u64 *__restrict__ src, size_t src_stride,
                                                                            double *__restrict__ part, int nl, int per_target,
                                                                            u32 gelt) {
@@ -592,7 +592,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCt
     const Mod m = mod_at(c, j);
     const FpTable t = fp_table(c, j);
     ntt_inv_block_a<LB, FpArith>(
-        lds, [&](int, int i) { return fp_from_u64(sp[galois_ntt_src((u32)i, gelt, LB)]); },  // gelt: rotation folded in
+        lds, [&](int, int i) { return fp_from_u64(sp[galois_ntt_src<GAL>((u32)i, gelt, LB)]); },  // gelt: rotation folded in
         [&](int r, int, double v) {
           double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
           x[r] = w < 0.0 ? w + m.qd : w;
@@ -622,6 +622,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCt
 
 // K2s: workgroup (ct, I, block): x_J = stages 4..13 of the half-done limb (ct, I, J) on this 1024-point block (for
 // J = I, CKKS: the operand's own NTT form), acc_c += x_J * key[J][c][I]; canonical sums to ksacc / tsp.
+template <bool GAL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_fused_tailmac_fp(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ ntt,
                                                          size_t ntt_stride, const u64 *__restrict__ key, u64 *__restrict__ ksacc,
                                                          u64 *__restrict__ tsp, int nl, u32 gelt) {
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int i = 4 * (tid + 64 * g) + k;
-          accum(4 * g + k, i, fp_from_u64(xl[galois_ntt_src((u32)((blk << 10) + i), gelt, c.logn)]));
+          accum(4 * g + k, i, fp_from_u64(xl[galois_ntt_src<GAL>((u32)((blk << 10) + i), gelt, c.logn)]));
         }
     } else {
       const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
@@ -677,6 +678,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
 // takes the diagonal operand), multiplies by its two key slices and adds the products into two LDS accumulators
 // (ds_add_f64: sums of integer-valued doubles below 2^53 are exact in any order).  The nl operand loads of an item are
 // in flight together and no wavefront carries accumulators, so it runs at four wavefronts per SIMD.
+template <bool GAL>
 __global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const double *__restrict__ part,
                                                                 const u64 *__restrict__ ntt, size_t ntt_stride,
                                                                 const u64 *__restrict__ key, u64 *__restrict__ ksacc,
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const 
     for (int g = 0; g < 4; g++)
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        x[4 * g + k] = fp_from_u64(xl[galois_ntt_src((u32)((blk << 10) + 4 * (lane + 64 * g) + k), gelt, c.logn)]);
+        x[4 * g + k] = fp_from_u64(xl[galois_ntt_src<GAL>((u32)((blk << 10) + 4 * (lane + 64 * g) + k), gelt, c.logn)]);
   } else {
     const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
     ntt_fwd_block_a<10, FpArith>(
@@ -794,18 +796,21 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
       hipLaunchKernelGGL(k_fused_ks_decomp_ntt_fp<LB>, dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
     // cooperative form: nl wavefronts and 8.5 max(nl, 2) KiB of LDS per workgroup
     if (dec_ready == 2 && nl <= 12 && !std::getenv("ABC_HIP_TAILMAC_SERIAL"))
-      hipLaunchKernelGGL(k_fused_tailmac_coop_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64 * nl),
+      hipLaunchKernelGGL((gelt ? k_fused_tailmac_coop_fp<true> : k_fused_tailmac_coop_fp<false>), dim3((unsigned)(cc * (nl + 1) * 16)),
+                         dim3(64 * nl),
                          (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8, st, c->dc, (const double *)s.dec,
                          ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, gelt);
     else if (dec_ready == 2)
-      hipLaunchKernelGGL(k_fused_tailmac_fp, dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64), 0, st, c->dc, (const double *)s.dec,
+      hipLaunchKernelGGL((gelt ? k_fused_tailmac_fp<true> : k_fused_tailmac_fp<false>), dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64), 0,
+                         st, c->dc, (const double *)s.dec,
                          ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, gelt);
     else
       hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
                          ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
     hipLaunchKernelGGL(k_fused_ks_special_intt_fp<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, s.tsp, s.tlast);
     if (ckks)
-      hipLaunchKernelGGL(k_fused_ks_moddown_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
+      hipLaunchKernelGGL((gelt ? k_fused_ks_moddown_fp<LB, true> : k_fused_ks_moddown_fp<LB, false>), dim3(g3), block, 0, st, c->dc,
+                         s.ksacc, s.tlast, addend, addend_stride,
                          add_c1 ? 1 : 0, out, nl, (int)(cc * 2), gelt);
     else
       hipLaunchKernelGGL(k_fused_ks_moddown_bfv_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
@@ -973,13 +978,14 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     if constexpr (LB == 14) {
       split = all_fp(c) && !std::getenv("ABC_HIP_NO_SPLIT");
       if (split && ckks)
-        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, true>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
-                           target_stride, (double *)s.dec, nl, 0, gelt);
+        hipLaunchKernelGGL((gelt ? k_fused_operand_pass0_fp<LB, true, true> : k_fused_operand_pass0_fp<LB, true, false>),
+                           dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, 0,
+                           gelt);
       else if (split && cc * nl < 128)
-        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false>), dim3((unsigned)(cc * nl * (nl + 1))), dim3((1 << LB) / 16), 0, st,
+        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl * (nl + 1))), dim3((1 << LB) / 16), 0, st,
                            c->dc, tg, target_stride, (double *)s.dec, nl, 1, 0u);
       else if (split)
-        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
+        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
                            target_stride, (double *)s.dec, nl, 0, 0u);
     }
     if (split) {

@@ -136,9 +136,11 @@ __device__ __forceinline__ u32 bitrev32(u32 x, int bits) { return __brev(x) >> (
 // Galois automorphism x -> x^elt on an NTT-form limb (SEAL bit-reversed order) as a gather: slot i holds the evaluation
 // at psi^(2 bitrev(i) + 1) and receives the slot holding that exponent times elt.  The map sends every aligned block of
 // 2^k slots onto an aligned block of 2^k slots (the high bits of the source depend only on the high bits of i), so a
-// wavefront that reads 64 consecutive slots gathers from one 512-byte segment.  elt = 0: identity.
+// wavefront that reads 64 consecutive slots gathers from one 512-byte segment.  GAL = false: identity, decided at
+// compile time (a run-time test per element would turn the callers' batched loads into a branch per word).
+template <bool GAL>
 __device__ __forceinline__ u32 galois_ntt_src(u32 i, u32 elt, int logn) {
-  if (!elt) return i;
+  if (!GAL) return i;
   const u32 rev = bitrev32(i + (1u << logn), logn + 1);
   const u32 idx = (u32)((((u64)elt * rev) >> 1) & (u64)((1u << logn) - 1));
   return bitrev32(idx, logn);
