@@ -43,31 +43,42 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv(DevCtx c, u64 *data,
 
 // fp64 variants (every prime of the launch below 2^50, whole transform in one block): same memory format, the
 // conversion u64 <-> double happens in the load / store functors.
+// S0 > 0: block b of a larger transform whose first S0 stages a strided fp64 pass has done; the hand-off buffer holds
+// raw doubles (lazy residues), re-centred on the way in.
 template <int LB>
-__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd_fp(DevCtx c, u64 *data, const u64 *src, LimbMap map, int nl) {
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd_fp(DevCtx c, u64 *data, const u64 *src, LimbMap map, int nl, int S0) {
   __shared__ double lds[lds_words(LB)];
-  const size_t limb = blockIdx.x;
+  const size_t limb = blockIdx.x >> S0;
+  const int b = blockIdx.x & ((1 << S0) - 1);
   const int mid = map.id[limb % nl];
-  const Mod m = c.mods[mid];
+  const Mod m = mod_at(c, mid);
   const FpTable t = fp_table(c, mid);
-  u64 *base = data + limb * (size_t)c.n;
-  const u64 *in = src + limb * (size_t)c.n;  // == base for an in-place transform
-  ntt_fwd_block_a<LB, FpArith>(
-      lds, [&](int, int i) { return fp_from_u64(in[i]); }, [&](int, int i, double v) { base[i] = fp_to_canon(v, m.qd, m.qinv); },
-      t, m, 0, 0);
+  u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
+  const u64 *in = src + limb * (size_t)c.n + ((size_t)b << LB);  // == base for an in-place transform
+  auto st = [&](int, int i, double v) { base[i] = fp_to_canon(v, m.qd, m.qinv); };
+  if (S0 == 0)
+    ntt_fwd_block_a<LB, FpArith>(lds, [&](int, int i) { return fp_from_u64(in[i]); }, st, t, m, 0, 0);
+  else
+    ntt_fwd_block_a<LB, FpArith>(
+        lds, [&](int, int i) { return fp_centre(reinterpret_cast<const double *>(in)[i], m.qd, m.qinv); }, st, t, m, S0, b);
 }
 
 template <int LB>
-__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv_fp(DevCtx c, u64 *data, LimbMap map, int nl) {
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv_fp(DevCtx c, u64 *data, LimbMap map, int nl, int S0) {
   __shared__ double lds[lds_words(LB)];
-  const size_t limb = blockIdx.x;
+  const size_t limb = blockIdx.x >> S0;
+  const int b = blockIdx.x & ((1 << S0) - 1);
   const int mid = map.id[limb % nl];
-  const Mod m = c.mods[mid];
+  const Mod m = mod_at(c, mid);
   const FpTable t = fp_table(c, mid);
-  u64 *base = data + limb * (size_t)c.n;
-  ntt_inv_block_a<LB, FpArith>(
-      lds, [&](int, int i) { return fp_from_u64(base[i]); },
-      [&](int, int i, double v) { base[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv); }, t, m, 0, 0);
+  u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
+  auto ld = [&](int, int i) { return fp_from_u64(base[i]); };
+  if (S0 == 0)
+    ntt_inv_block_a<LB, FpArith>(
+        lds, ld, [&](int, int i, double v) { base[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv); }, t, m,
+        0, 0);
+  else  // the strided pass finishes the transform: hand over raw doubles (|x| <= 16 q after the last block pass)
+    ntt_inv_block_a<LB, FpArith>(lds, ld, [&](int, int i, double v) { reinterpret_cast<double *>(base)[i] = v; }, t, m, S0, b);
 }
 
 // first R stages of a 2^logn-point forward transform, straight through HBM (coalesced: lane = p)
@@ -134,7 +145,74 @@ __global__ __launch_bounds__(256) void k_ntt_inv_strided(DevCtx c, u64 *data, Li
   for (int k = 0; k < (1 << R); k++) base[(size_t)k * G] = scale_inv_n(x[k], m);
 }
 
+// fp64 twins of the two strided passes (every prime of the launch below 2^50).  Forward: u64 in, raw doubles out
+// (R <= 4 stages from a canonical input stay below 4.1 q even for 50-bit primes).  Inverse: raw doubles in, re-centred,
+// R stages, N^-1, canonical u64 out.
+template <int R>
+__global__ __launch_bounds__(256) void k_ntt_fwd_strided_fp(DevCtx c, u64 *data, LimbMap map, int nl) {
+  const int G = c.n >> R;
+  const int per = G / 256;
+  const size_t limb = blockIdx.x / per;
+  const int p = (blockIdx.x % per) * 256 + threadIdx.x;
+  const int mid = map.id[limb % nl];
+  const Mod m = mod_at(c, mid);
+  const FpTable t = fp_table(c, mid);
+  u64 *base = data + limb * (size_t)c.n + p;
+  double x[1 << R];
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) x[k] = fp_from_u64(base[(size_t)k * G]);
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      const f64x2 tp = tw_load(t.tw + (1 << u) + (k >> (R - u)));
+      const double a = x[k], v = fp_mul_lazy(x[k | half], tp.x, tp.y, m.qd);
+      x[k] = a + v;
+      x[k | half] = a - v;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) reinterpret_cast<double *>(base)[(size_t)k * G] = x[k];
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_ntt_inv_strided_fp(DevCtx c, u64 *data, LimbMap map, int nl) {
+  const int G = c.n >> R;
+  const int per = G / 256;
+  const size_t limb = blockIdx.x / per;
+  const int p = (blockIdx.x % per) * 256 + threadIdx.x;
+  const int mid = map.id[limb % nl];
+  const Mod m = mod_at(c, mid);
+  const FpTable t = fp_table(c, mid);
+  u64 *base = data + limb * (size_t)c.n + p;
+  double x[1 << R];
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) x[k] = fp_centre(reinterpret_cast<const double *>(base)[(size_t)k * G], m.qd, m.qinv);
+#pragma unroll
+  for (int u = R - 1; u >= 0; u--) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      const f64x2 tp = tw_load(t.itw + (1 << u) + (k >> (R - u)));
+      const double a = x[k], b2 = x[k | half];
+      x[k] = a + b2;  // at most 2^R * q/2 = 8 q after R = 4 stages
+      x[k | half] = fp_mul_lazy(a - b2, tp.x, tp.y, m.qd);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++)
+    base[(size_t)k * G] = fp_to_canon(fp_mul_lazy(x[k], m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
+}
+
 constexpr int kBigBlockLB = 12;  // LDS block size used under the strided pass for N > 2^14
+
+static bool all_limbs_fp(const abc_hip_ctx *c, const LimbMap &map, int nl) {
+  bool fp = c->use_fp;
+  for (int j = 0; j < nl; j++) fp = fp && fp_ok(c->h_mods[map.id[j]].bits);
+  return fp;
+}
 
 template <int LB>
 static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, int S0, bool fwd,
@@ -143,15 +221,13 @@ static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size
   dim3 grid((unsigned)(total_limbs << S0)), block((1 << LB) / 16);
   // every limb of the launch must allow the unguarded butterflies; the strided pre-pass (S0 > 0) already
   // spent part of the headroom, keep the guard there
-  bool guard = (S0 != 0), fp = (S0 == 0) && c->use_fp;
-  for (int j = 0; j < nl; j++) {
-    guard = guard || !unguarded_ok(c->h_mods[map.id[j]].bits);
-    fp = fp && fp_ok(c->h_mods[map.id[j]].bits);
-  }
+  bool guard = (S0 != 0);
+  const bool fp = all_limbs_fp(c, map, nl);  // with S0 > 0 the strided pass of the same launch makes the same choice
+  for (int j = 0; j < nl; j++) guard = guard || !unguarded_ok(c->h_mods[map.id[j]].bits);
   if (fp && fwd)
-    hipLaunchKernelGGL(k_ntt_fwd_fp<LB>, grid, block, 0, c->stream, c->dc, d, src, map, nl);
+    hipLaunchKernelGGL(k_ntt_fwd_fp<LB>, grid, block, 0, c->stream, c->dc, d, src, map, nl, S0);
   else if (fp)
-    hipLaunchKernelGGL(k_ntt_inv_fp<LB>, grid, block, 0, c->stream, c->dc, d, map, nl);
+    hipLaunchKernelGGL(k_ntt_inv_fp<LB>, grid, block, 0, c->stream, c->dc, d, map, nl, S0);
   else if (fwd && guard)
     hipLaunchKernelGGL((k_ntt_fwd<LB, true>), grid, block, 0, c->stream, c->dc, d, src, map, nl, S0);
   else if (fwd)
@@ -166,8 +242,13 @@ template <int R>
 static int launch_strided(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd) {
   const int G = c->n >> R;
   dim3 grid((unsigned)(total_limbs * (G / 256))), block(256);
-  if (fwd)
+  const bool fp = all_limbs_fp(c, map, nl);
+  if (fwd && fp)
+    hipLaunchKernelGGL(k_ntt_fwd_strided_fp<R>, grid, block, 0, c->stream, c->dc, d, map, nl);
+  else if (fwd)
     hipLaunchKernelGGL(k_ntt_fwd_strided<R>, grid, block, 0, c->stream, c->dc, d, map, nl);
+  else if (fp)
+    hipLaunchKernelGGL(k_ntt_inv_strided_fp<R>, grid, block, 0, c->stream, c->dc, d, map, nl);
   else
     hipLaunchKernelGGL(k_ntt_inv_strided<R>, grid, block, 0, c->stream, c->dc, d, map, nl);
   ABC_HIP_CHECK(hipGetLastError());
