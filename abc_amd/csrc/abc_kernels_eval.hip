@@ -209,9 +209,13 @@ int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, c
       tc = tcoef;
       tcs = nl * N;
     }
-    hipLaunchKernelGGL(k_ks_expand, dim3(grid_for(cc * nl * N, 256)), dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl, cc);
-    ABC_HIP_CHECK(hipGetLastError());
-    if (launch_ntt_fwd(c, dec, dmap, nl + 1, cc * nl * (nl + 1))) return 1;
+    const int fused_expand = launch_ks_expand_ntt_fp(c, tc, tcs, dec, dmap, nl, cc);
+    if (fused_expand > 0) return 1;
+    if (fused_expand < 0) {
+      hipLaunchKernelGGL(k_ks_expand, dim3(grid_for(cc * nl * N, 256)), dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl, cc);
+      ABC_HIP_CHECK(hipGetLastError());
+      if (launch_ntt_fwd(c, dec, dmap, nl + 1, cc * nl * (nl + 1))) return 1;
+    }
     hipLaunchKernelGGL(k_ks_inner, dim3(grid_for(cc * (nl + 1) * N, 256)), dim3(256), 0, c->stream, c->dc, dec, key, prodD,
                        prodS, nl, cc);
     ABC_HIP_CHECK(hipGetLastError());

@@ -306,6 +306,58 @@ static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t
   }
 }
 
+// Key-switch decomposition for N > 2^14, fp64 primes: the strided pass reads operand limb J once per target prime I
+// straight from the operand (no reduction modulo q_I is needed in fp64) and writes the half-done limb (ct, J, I), the
+// block kernel finishes it -- the separate expand kernel and its round trip disappear.
+// dec[ct][J][I] for I <= nl (I = nl: the special prime).  -1: not applicable.
+template <int R>
+__global__ __launch_bounds__(256) void k_ks_expand_strided_fp(DevCtx c, const u64 *__restrict__ tcoef, size_t tstride,
+                                                              u64 *__restrict__ dec, LimbMap map, int nl) {
+  const int G = c.n >> R;
+  const int per = G / 256;
+  const size_t limb = blockIdx.x / per;  // (ct * nl + J) * (nl + 1) + I
+  const int p = (blockIdx.x % per) * 256 + threadIdx.x;
+  const int I = (int)(limb % (size_t)(nl + 1));
+  const size_t cj = limb / (size_t)(nl + 1);
+  const int J = (int)(cj % (size_t)nl);
+  const size_t ct = cj / (size_t)nl;
+  const int mid = map.id[I];
+  const Mod m = mod_at(c, mid);
+  const FpTable t = fp_table(c, mid);
+  const u64 *__restrict__ src = tcoef + ct * tstride + (size_t)J * c.n + p;
+  double *__restrict__ dst = reinterpret_cast<double *>(dec) + limb * (size_t)c.n + p;
+  double x[1 << R];
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) x[k] = fp_from_u64(src[(size_t)k * G]);
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      const f64x2 tp = tw_load(t.tw + (1 << u) + (k >> (R - u)));
+      const double a = x[k], v = fp_mul_lazy(x[k | half], tp.x, tp.y, m.qd);
+      x[k] = a + v;
+      x[k | half] = a - v;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) dst[(size_t)k * G] = x[k];
+}
+int launch_ks_expand_ntt_fp(abc_hip_ctx *c, const u64 *tcoef, size_t tstride, u64 *dec, const LimbMap &map, int nl, size_t count) {
+  if (c->logn <= 14 || !all_limbs_fp(c, map, nl + 1)) return -1;
+  const int S0 = c->logn - kBigBlockLB;
+  const size_t limbs = count * nl * (nl + 1);
+  const int G = c->n >> S0;
+  const dim3 grid((unsigned)(limbs * (G / 256))), block(256);
+  if (S0 == 3)
+    hipLaunchKernelGGL(k_ks_expand_strided_fp<3>, grid, block, 0, c->stream, c->dc, tcoef, tstride, dec, map, nl);
+  else
+    hipLaunchKernelGGL(k_ks_expand_strided_fp<4>, grid, block, 0, c->stream, c->dc, tcoef, tstride, dec, map, nl);
+  ABC_HIP_CHECK(hipGetLastError());
+  return launch_block<kBigBlockLB>(c, dec, map, nl + 1, limbs, S0, true);
+}
+
 int launch_ntt_fwd(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
   return launch_ntt(c, d, map, nl, total_limbs, true);
 }
