@@ -156,6 +156,7 @@ LimbMap key_limb_map(const abc_hip_ctx *c, int nl);  // 0..nl-1 -> data primes, 
 // group uses modulus map.id[j % nl]
 int launch_ntt_fwd(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
 int launch_ks_expand_ntt_fp(abc_hip_ctx *c, const u64 *tcoef, size_t tstride, u64 *dec, const LimbMap &map, int nl, size_t count);
+int launch_ntt_fwd_from2(abc_hip_ctx *c, const u64 *src, const u64 *src2, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
 int launch_ntt_fwd_from(abc_hip_ctx *c, const u64 *src, u64 *d, const LimbMap &map, int nl, size_t total_limbs);  // out of place
 int launch_ntt_inv(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
 

@@ -64,19 +64,23 @@ __device__ __forceinline__ u64 canon_dot(u64 v, const Mod &m) { return m.bits > 
 // constants arrive in batched scalar loads instead of one dependent s_load per inner iteration (the runtime-bound
 // form is latency-bound on exactly that: 0.94 ms -> see DESIGN.md).  LT = 0: any shape.
 template <int LT, int NBT>
-__global__ __launch_bounds__(256) void k_behz_extend(DevCtx c, const u64 *in, u64 *out, size_t polys) {
+__global__ __launch_bounds__(256) void k_behz_extend(DevCtx c, const u64 *in, const u64 *in2, u64 *out, size_t polys) {
   const ABC_CONST_AS DevConst &k = *(const ABC_CONST_AS DevConst *)c.cst;  // constants never change: scalar loads
   const int L = LT ? LT : k.nq, nBsk = LT ? NBT + 1 : k.nBsk;
   const size_t items = polys * c.n;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
     const size_t p = it >> c.logn, x = it & (c.n - 1);
+    // polynomials [0, polys/2) come from `in`, the rest from `in2` (both operands of a multiply in one launch)
+    const bool second = in2 && p >= polys / 2;
+    const u64 *src = second ? in2 : in;
+    const size_t pp = second ? p - polys / 2 : p;
     u64 tmp[LT ? LT : kMaxLimbs];
     u32 mt = 0;
 #pragma unroll
     for (int i = 0; i < L; i++) {
       // * m~ * (q/q_i)^-1 as one constant (canonical result, so identical to the two-step product)
-      const u64 v = mul_shoup(in[(p * L + i) * c.n + x], k.ext_q[i], k.ext_q_s[i], mod_at(c, i).q);
+      const u64 v = mul_shoup(src[(pp * L + i) * c.n + x], k.ext_q[i], k.ext_q_s[i], mod_at(c, i).q);
       tmp[i] = v;
       mt += (u32)v * (u32)k.q_to_mtilde[i];  // arithmetic mod 2^32
     }
@@ -250,8 +254,8 @@ static int tensor_intt(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d, const
     else if (L_ == 8 && nB_ == 8) hipLaunchKernelGGL((KERNEL<8, 8>), GRID, dim3(256), 0, c->stream, __VA_ARGS__);       \
     else hipLaunchKernelGGL((KERNEL<0, 0>), GRID, dim3(256), 0, c->stream, __VA_ARGS__);                                \
   } while (0)
-static void launch_behz_extend(abc_hip_ctx *c, const u64 *in, u64 *out, size_t polys) {
-  ABC_BEHZ_DISPATCH(k_behz_extend, dim3(grid_for(polys * c->n, 256)), c->dc, in, out, polys);
+static void launch_behz_extend(abc_hip_ctx *c, const u64 *in, const u64 *in2, u64 *out, size_t polys) {
+  ABC_BEHZ_DISPATCH(k_behz_extend, dim3(grid_for(polys * c->n, 256)), c->dc, in, in2, out, polys);
 }
 static void launch_behz_floor(abc_hip_ctx *c, const u64 *dq, const u64 *dB, u64 *out, size_t polys) {
   ABC_BEHZ_DISPATCH(k_behz_floor, dim3(grid_for(polys * c->n, 256)), c->dc, dq, dB, out, polys);
@@ -279,11 +283,10 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
   for (size_t off = 0; off < count; off += chunk) {
     const size_t cc = (count - off < chunk) ? count - off : chunk;
     const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
-    launch_behz_extend(c, pa, aB, cc * 2);
-    launch_behz_extend(c, pb, bB, cc * 2);
+    launch_behz_extend(c, pa, pb, aB, cc * 4);  // aB and bB are adjacent: one launch for both operands
     ABC_HIP_CHECK(hipGetLastError());
-    if (launch_ntt_fwd_from(c, pa, aq, qmap, L, cc * 2 * L)) return 1;  // operands stay intact: transform out of place
-    if (launch_ntt_fwd_from(c, pb, bq, qmap, L, cc * 2 * L)) return 1;
+    // operands stay intact: transform out of place, both operands in one launch (aq and bq are adjacent)
+    if (launch_ntt_fwd_from2(c, pa, pb, aq, qmap, L, cc * 4 * L)) return 1;
     if (launch_ntt_fwd(c, aB, bmap, nBsk, cc * 4 * nBsk)) return 1;    // aB and bB are adjacent
     int rq = tensor_intt(c, aq, bq, dq, qmap, L, cc);
     if (rq > 0) return 1;

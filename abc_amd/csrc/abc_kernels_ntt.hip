@@ -13,7 +13,7 @@
 namespace abc {
 
 template <int LB, bool GUARD>
-__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data, const u64 *src, LimbMap map, int nl, int S0) {
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data, const u64 *src, const u64 *src2, size_t split, LimbMap map, int nl, int S0) {
   __shared__ u64 lds[lds_words(LB)];
   const size_t limb = blockIdx.x >> S0;
   const int b = blockIdx.x & ((1 << S0) - 1);
@@ -21,7 +21,8 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd(DevCtx c, u64 *data,
   const Mod m = c.mods[mid];
   const NttTable t = ntt_table(c, mid);
   u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
-  const u64 *in = src + limb * (size_t)c.n + ((size_t)b << LB);  // == base for an in-place transform
+  // limbs [0, split) are read from src, the rest from src2 (two operands, one launch); in place: src == data
+  const u64 *in = (limb < split ? src + limb * (size_t)c.n : src2 + (limb - split) * (size_t)c.n) + ((size_t)b << LB);
   ntt_fwd_block<LB, GUARD>(
       lds, [&](int, int i) { return in[i]; }, [&](int, int i, u64 v) { base[i] = canon_fwd<GUARD>(v, m); }, t, m, S0, b);
 }
@@ -46,7 +47,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv(DevCtx c, u64 *data,
 // S0 > 0: block b of a larger transform whose first S0 stages a strided fp64 pass has done; the hand-off buffer holds
 // raw doubles (lazy residues), re-centred on the way in.
 template <int LB>
-__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd_fp(DevCtx c, u64 *data, const u64 *src, LimbMap map, int nl, int S0) {
+__global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd_fp(DevCtx c, u64 *data, const u64 *src, const u64 *src2, size_t split, LimbMap map, int nl, int S0) {
   __shared__ double lds[lds_words(LB)];
   const size_t limb = blockIdx.x >> S0;
   const int b = blockIdx.x & ((1 << S0) - 1);
@@ -54,7 +55,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_fwd_fp(DevCtx c, u64 *da
   const Mod m = mod_at(c, mid);
   const FpTable t = fp_table(c, mid);
   u64 *base = data + limb * (size_t)c.n + ((size_t)b << LB);
-  const u64 *in = src + limb * (size_t)c.n + ((size_t)b << LB);  // == base for an in-place transform
+  const u64 *in = (limb < split ? src + limb * (size_t)c.n : src2 + (limb - split) * (size_t)c.n) + ((size_t)b << LB);
   auto st = [&](int, int i, double v) { base[i] = fp_to_canon(v, m.qd, m.qinv); };
   if (S0 == 0)
     ntt_fwd_block_a<LB, FpArith>(lds, [&](int, int i) { return fp_from_u64(in[i]); }, st, t, m, 0, 0);
@@ -216,8 +217,9 @@ static bool all_limbs_fp(const abc_hip_ctx *c, const LimbMap &map, int nl) {
 
 template <int LB>
 static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, int S0, bool fwd,
-                        const u64 *src = nullptr) {
+                        const u64 *src = nullptr, const u64 *src2 = nullptr) {
   if (!src) src = d;
+  const size_t split = src2 ? total_limbs / 2 : total_limbs;  // two sources: first half of the limbs from src, second from src2
   dim3 grid((unsigned)(total_limbs << S0)), block((1 << LB) / 16);
   // every limb of the launch must allow the unguarded butterflies; the strided pre-pass (S0 > 0) already
   // spent part of the headroom, keep the guard there
@@ -225,13 +227,13 @@ static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size
   const bool fp = all_limbs_fp(c, map, nl);  // with S0 > 0 the strided pass of the same launch makes the same choice
   for (int j = 0; j < nl; j++) guard = guard || !unguarded_ok(c->h_mods[map.id[j]].bits);
   if (fp && fwd)
-    hipLaunchKernelGGL(k_ntt_fwd_fp<LB>, grid, block, 0, c->stream, c->dc, d, src, map, nl, S0);
+    hipLaunchKernelGGL(k_ntt_fwd_fp<LB>, grid, block, 0, c->stream, c->dc, d, src, src2, split, map, nl, S0);
   else if (fp)
     hipLaunchKernelGGL(k_ntt_inv_fp<LB>, grid, block, 0, c->stream, c->dc, d, map, nl, S0);
   else if (fwd && guard)
-    hipLaunchKernelGGL((k_ntt_fwd<LB, true>), grid, block, 0, c->stream, c->dc, d, src, map, nl, S0);
+    hipLaunchKernelGGL((k_ntt_fwd<LB, true>), grid, block, 0, c->stream, c->dc, d, src, src2, split, map, nl, S0);
   else if (fwd)
-    hipLaunchKernelGGL((k_ntt_fwd<LB, false>), grid, block, 0, c->stream, c->dc, d, src, map, nl, S0);
+    hipLaunchKernelGGL((k_ntt_fwd<LB, false>), grid, block, 0, c->stream, c->dc, d, src, src2, split, map, nl, S0);
   else
     hipLaunchKernelGGL(k_ntt_inv<LB>, grid, block, 0, c->stream, c->dc, d, map, nl, S0);
   ABC_HIP_CHECK(hipGetLastError());
@@ -257,26 +259,35 @@ static int launch_strided(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, si
 
 // src != nullptr (forward only): read the coefficients from src, write the transform to d (saves a copy where the
 // operand must survive); rings that need the strided pre-pass copy first.
-static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd, const u64 *src = nullptr) {
+static int copy_sources(abc_hip_ctx *c, u64 *d, const u64 *src, const u64 *src2, size_t total_limbs) {
+  const size_t first = src2 ? total_limbs / 2 : total_limbs;
+  ABC_HIP_CHECK(hipMemcpyAsync(d, src, first * (size_t)c->n * 8, hipMemcpyDeviceToDevice, c->stream));
+  if (src2)
+    ABC_HIP_CHECK(hipMemcpyAsync(d + first * (size_t)c->n, src2, (total_limbs - first) * (size_t)c->n * 8, hipMemcpyDeviceToDevice,
+                                 c->stream));
+  return 0;
+}
+static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd, const u64 *src = nullptr,
+                      const u64 *src2 = nullptr) {
   if (total_limbs == 0) return 0;
   if (src && (c->logn > 14 || !fwd)) {
-    ABC_HIP_CHECK(hipMemcpyAsync(d, src, total_limbs * (size_t)c->n * 8, hipMemcpyDeviceToDevice, c->stream));
-    src = nullptr;
+    if (copy_sources(c, d, src, src2, total_limbs)) return 1;
+    src = src2 = nullptr;
   }
   switch (c->logn) {
-    case 10: return launch_block<10>(c, d, map, nl, total_limbs, 0, fwd, src);
-    case 11: return launch_block<11>(c, d, map, nl, total_limbs, 0, fwd, src);
-    case 12: return launch_block<12>(c, d, map, nl, total_limbs, 0, fwd, src);
-    case 13: return launch_block<13>(c, d, map, nl, total_limbs, 0, fwd, src);
+    case 10: return launch_block<10>(c, d, map, nl, total_limbs, 0, fwd, src, src2);
+    case 11: return launch_block<11>(c, d, map, nl, total_limbs, 0, fwd, src, src2);
+    case 12: return launch_block<12>(c, d, map, nl, total_limbs, 0, fwd, src, src2);
+    case 13: return launch_block<13>(c, d, map, nl, total_limbs, 0, fwd, src, src2);
     case 14: {
       // few limbs in flight (single-ciphertext calls): one workgroup per limb leaves most CUs idle for 17-30 us per
       // transform; spread each transform over 64 + 16 workgroups instead (strided radix-16 pass through HBM +
       // 1024-point blocks, the N > 2^14 machinery), trading an HBM round trip nobody misses at this size
       static const size_t few = std::getenv("ABC_HIP_FEW_LIMBS") ? (size_t)std::atol(std::getenv("ABC_HIP_FEW_LIMBS")) : 48;
-      if (total_limbs > few) return launch_block<14>(c, d, map, nl, total_limbs, 0, fwd, src);
+      if (total_limbs > few) return launch_block<14>(c, d, map, nl, total_limbs, 0, fwd, src, src2);
       if (src) {
-        ABC_HIP_CHECK(hipMemcpyAsync(d, src, total_limbs * (size_t)c->n * 8, hipMemcpyDeviceToDevice, c->stream));
-        src = nullptr;
+        if (copy_sources(c, d, src, src2, total_limbs)) return 1;
+        src = src2 = nullptr;
       }
       if (fwd) {
         if (int rc = launch_strided<4>(c, d, map, nl, total_limbs, true)) return rc;
@@ -363,6 +374,10 @@ int launch_ntt_fwd(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t to
 }
 int launch_ntt_fwd_from(abc_hip_ctx *c, const u64 *src, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
   return launch_ntt(c, d, map, nl, total_limbs, true, src);
+}
+// first half of the limbs from src, second half from src2 (total_limbs even)
+int launch_ntt_fwd_from2(abc_hip_ctx *c, const u64 *src, const u64 *src2, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
+  return launch_ntt(c, d, map, nl, total_limbs, true, src, src2);
 }
 int launch_ntt_inv(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
   return launch_ntt(c, d, map, nl, total_limbs, false);
