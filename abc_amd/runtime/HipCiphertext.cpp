@@ -76,40 +76,40 @@ int HipCiphertext::noiseBits() const {
 // ---- ctxt-ctxt ----
 std::unique_ptr<AbstractCiphertext> HipCiphertext::add(const AbstractCiphertext &operand) const {
   auto r = fresh();
-  abcHipCheck(abc_hip_add(getFactory().context(), d_data, cast(operand).d_data, r->d_data, 2, getFactory().dataLimbs(), 1), "add");
+  abcHipCheck(abc_hip_add(getFactory().context(), d_data, cast(operand).d_data, r->d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "add");
   return r;
 }
 std::unique_ptr<AbstractCiphertext> HipCiphertext::subtract(const AbstractCiphertext &operand) const {
   auto r = fresh();
-  abcHipCheck(abc_hip_sub(getFactory().context(), d_data, cast(operand).d_data, r->d_data, 2, getFactory().dataLimbs(), 1), "sub");
+  abcHipCheck(abc_hip_sub(getFactory().context(), d_data, cast(operand).d_data, r->d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "sub");
   return r;
 }
 std::unique_ptr<AbstractCiphertext> HipCiphertext::multiply(const AbstractCiphertext &operand) const {
   // Evaluator::multiply + relinearize_inplace, src/runtime/SealCiphertext.cpp:102-107
   auto r = fresh();
-  abcHipCheck(abc_hip_mul_relin(getFactory().context(), d_data, cast(operand).d_data, r->d_data, getFactory().dataLimbs(), 1),
+  abcHipCheck(abc_hip_mul_relin(getFactory().context(), d_data, cast(operand).d_data, r->d_data, getFactory().dataLimbs(), getFactory().batchSize()),
               "multiply");
   return r;
 }
 void HipCiphertext::addInplace(const AbstractCiphertext &operand) {
-  abcHipCheck(abc_hip_add(getFactory().context(), d_data, cast(operand).d_data, d_data, 2, getFactory().dataLimbs(), 1), "add");
+  abcHipCheck(abc_hip_add(getFactory().context(), d_data, cast(operand).d_data, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "add");
 }
 void HipCiphertext::subtractInplace(const AbstractCiphertext &operand) {
-  abcHipCheck(abc_hip_sub(getFactory().context(), d_data, cast(operand).d_data, d_data, 2, getFactory().dataLimbs(), 1), "sub");
+  abcHipCheck(abc_hip_sub(getFactory().context(), d_data, cast(operand).d_data, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "sub");
 }
 void HipCiphertext::multiplyInplace(const AbstractCiphertext &operand) {
-  abcHipCheck(abc_hip_mul_relin(getFactory().context(), d_data, cast(operand).d_data, d_data, getFactory().dataLimbs(), 1),
+  abcHipCheck(abc_hip_mul_relin(getFactory().context(), d_data, cast(operand).d_data, d_data, getFactory().dataLimbs(), getFactory().batchSize()),
               "multiply");
 }
 
 // ---- rotation ----
 std::unique_ptr<AbstractCiphertext> HipCiphertext::rotateRows(int steps) const {
   auto r = fresh();
-  abcHipCheck(abc_hip_rotate(getFactory().context(), d_data, r->d_data, getFactory().dataLimbs(), steps, 1), "rotate_rows");
+  abcHipCheck(abc_hip_rotate(getFactory().context(), d_data, r->d_data, getFactory().dataLimbs(), steps, getFactory().batchSize()), "rotate_rows");
   return r;
 }
 void HipCiphertext::rotateRowsInplace(int steps) {
-  abcHipCheck(abc_hip_rotate(getFactory().context(), d_data, d_data, getFactory().dataLimbs(), steps, 1), "rotate_rows");
+  abcHipCheck(abc_hip_rotate(getFactory().context(), d_data, d_data, getFactory().dataLimbs(), steps, getFactory().batchSize()), "rotate_rows");
 }
 
 // ---- ctxt-plain ----
@@ -130,21 +130,21 @@ std::unique_ptr<AbstractCiphertext> HipCiphertext::multiplyPlain(const ICleartex
 }
 void HipCiphertext::addPlainInplace(const ICleartext &operand) {
   DevicePlain pl(getFactory(), intCleartext(operand, "ADD").getData());
-  abcHipCheck(abc_hip_add_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), 1), "add_plain");
+  abcHipCheck(abc_hip_add_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "add_plain");
 }
 void HipCiphertext::subtractPlainInplace(const ICleartext &operand) {
   DevicePlain pl(getFactory(), intCleartext(operand, "SUB").getData());
-  abcHipCheck(abc_hip_sub_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), 1), "sub_plain");
+  abcHipCheck(abc_hip_sub_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "sub_plain");
 }
 void HipCiphertext::multiplyPlainInplace(const ICleartext &operand) {
   const auto &ct = intCleartext(operand, "MULTIPLY");
   if (ct.allEqual(-1)) {  // negation shortcut, src/runtime/SealCiphertext.cpp:192-193
-    abcHipCheck(abc_hip_negate(getFactory().context(), d_data, d_data, 2, getFactory().dataLimbs(), 1), "negate");
+    abcHipCheck(abc_hip_negate(getFactory().context(), d_data, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "negate");
     return;
   }
   DevicePlain pl(getFactory(), ct.getData());
   // multiply_plain keeps size 2, so the reference's relinearize_inplace (:197) is a no-op
-  abcHipCheck(abc_hip_multiply_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), 1),
+  abcHipCheck(abc_hip_multiply_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()),
               "multiply_plain");
 }
 

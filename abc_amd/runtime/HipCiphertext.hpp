@@ -11,7 +11,7 @@
 #include "HipCiphertextFactory.hpp"
 
 class HipCiphertext : public AbstractCiphertext {
-  uint64_t *d_data = nullptr;  // device buffer [2][L][N]; owned
+  uint64_t *d_data = nullptr;  // device buffer [B][2][L][N] (B = the factory's batch size, 1 by default); owned
 
   std::unique_ptr<HipCiphertext> clone_impl() const;
   std::unique_ptr<HipCiphertext> fresh() const;

@@ -8,9 +8,17 @@
 
 HipCiphertextFactory::HipCiphertextFactory() { setupContext(0); }
 
-HipCiphertextFactory::HipCiphertextFactory(unsigned int numElementsPerCiphertextSlot, int device, uint64_t seed)
-    : ciphertextSlotSize(numElementsPerCiphertextSlot), keySeed(seed) {
+HipCiphertextFactory::HipCiphertextFactory(unsigned int numElementsPerCiphertextSlot, int device, uint64_t seed, size_t batchSize)
+    : ciphertextSlotSize(numElementsPerCiphertextSlot), keySeed(seed), batch(batchSize) {
+  if (!batch) throw std::runtime_error("HipCiphertextFactory: batch size must be at least 1");
   setupContext(device);
+}
+
+void HipCiphertextFactory::queueBatchedInput(std::vector<std::vector<int64_t>> perInstance) const {
+  if (perInstance.size() != batch)
+    throw std::runtime_error("queueBatchedInput: expected " + std::to_string(batch) + " vectors, got " +
+                             std::to_string(perInstance.size()));
+  queuedInputs.push_back(std::move(perInstance));
 }
 
 HipCiphertextFactory::~HipCiphertextFactory() { abc_hip_ctx_destroy(ctx); }
@@ -67,11 +75,33 @@ uint64_t *HipCiphertextFactory::createPlaintext(const std::vector<int> &value) c
 uint64_t *HipCiphertextFactory::createPlaintext(int64_t value) const { return createPlaintext(std::vector<int64_t>{value}); }
 
 std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCiphertext(const std::vector<int64_t> &data) const {
-  uint64_t *plain = createPlaintext(data);
+  // B rows of N slots: the queued per-instance vectors if there are any, else B copies of `data`
+  std::vector<int64_t> slots;
+  slots.reserve(batch * ciphertextSlotSize);
+  if (batch > 1 && !queuedInputs.empty()) {
+    for (const auto &row : queuedInputs.front()) {
+      const auto e = expandVector(row);
+      slots.insert(slots.end(), e.begin(), e.end());
+    }
+    queuedInputs.pop_front();
+  } else {
+    const auto e = expandVector(data);
+    for (size_t b = 0; b < batch; ++b) slots.insert(slots.end(), e.begin(), e.end());
+  }
+  const size_t bytes = slots.size() * 8;
+  void *d_vals = nullptr, *d_plain = nullptr;
+  abcHipCheck(abc_hip_malloc(ctx, &d_vals, bytes), "plaintext allocation");
+  if (abc_hip_malloc(ctx, &d_plain, bytes)) { abc_hip_free(ctx, d_vals); abcHipCheck(1, "plaintext allocation"); }
+  int rc = abc_hip_memcpy_h2d(ctx, d_vals, slots.data(), bytes);
+  if (!rc) rc = abc_hip_batch_encode(ctx, static_cast<const int64_t *>(d_vals), static_cast<uint64_t *>(d_plain), batch);
+  abc_hip_free(ctx, d_vals);
+  if (rc) { abc_hip_free(ctx, d_plain); abcHipCheck(rc, "batch encode"); }
   auto ctxt = std::make_unique<HipCiphertext>(std::cref(*this));
-  static uint64_t encryptionCounter = 0;  // distinct randomness per encryption
-  const int rc = abc_hip_encrypt(ctx, plain, keySeed * 0x9E3779B97F4A7C15ull + (++encryptionCounter), ctxt->devicePtr(), 1);
-  freeDevice(plain);
+  static uint64_t encryptionCounter = 0;  // distinct randomness per encryption (instance i uses seed + i)
+  encryptionCounter += batch;
+  rc = abc_hip_encrypt(ctx, static_cast<const uint64_t *>(d_plain), keySeed * 0x9E3779B97F4A7C15ull + encryptionCounter,
+                       ctxt->devicePtr(), batch);
+  abc_hip_free(ctx, d_plain);
   abcHipCheck(rc, "encrypt");
   return ctxt;
 }
@@ -91,19 +121,29 @@ std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCiphertext(std::
       "that only supports integers.");
 }
 
-void HipCiphertextFactory::decryptCiphertext(AbstractCiphertext &abstractCiphertext, std::vector<int64_t> &ciphertextData) const {
+void HipCiphertextFactory::decryptCiphertextBatch(AbstractCiphertext &abstractCiphertext,
+                                                  std::vector<std::vector<int64_t>> &out) const {
   auto &ctxt = dynamic_cast<HipCiphertext &>(abstractCiphertext);
-  const size_t bytes = (size_t)ciphertextSlotSize * 8;
+  const size_t words = batch * ciphertextSlotSize, bytes = words * 8;
   void *d_plain = nullptr, *d_vals = nullptr;
   abcHipCheck(abc_hip_malloc(ctx, &d_plain, bytes), "decrypt allocation");
-  abcHipCheck(abc_hip_malloc(ctx, &d_vals, bytes), "decrypt allocation");
-  int rc = abc_hip_decrypt(ctx, ctxt.devicePtr(), 2, limbs, static_cast<uint64_t *>(d_plain), 1);
-  if (!rc) rc = abc_hip_batch_decode(ctx, static_cast<const uint64_t *>(d_plain), static_cast<int64_t *>(d_vals), 1);
-  ciphertextData.resize(ciphertextSlotSize);
-  if (!rc) rc = abc_hip_memcpy_d2h(ctx, ciphertextData.data(), d_vals, bytes);  // synchronises: result observable on return
+  if (abc_hip_malloc(ctx, &d_vals, bytes)) { abc_hip_free(ctx, d_plain); abcHipCheck(1, "decrypt allocation"); }
+  int rc = abc_hip_decrypt(ctx, ctxt.devicePtr(), 2, limbs, static_cast<uint64_t *>(d_plain), batch);
+  if (!rc) rc = abc_hip_batch_decode(ctx, static_cast<const uint64_t *>(d_plain), static_cast<int64_t *>(d_vals), batch);
+  std::vector<int64_t> flat(words);
+  if (!rc) rc = abc_hip_memcpy_d2h(ctx, flat.data(), d_vals, bytes);  // synchronises: result observable on return
   abc_hip_free(ctx, d_plain);
   abc_hip_free(ctx, d_vals);
   abcHipCheck(rc, "decrypt");
+  out.assign(batch, {});
+  for (size_t b = 0; b < batch; ++b)
+    out[b].assign(flat.begin() + b * ciphertextSlotSize, flat.begin() + (b + 1) * ciphertextSlotSize);
+}
+
+void HipCiphertextFactory::decryptCiphertext(AbstractCiphertext &abstractCiphertext, std::vector<int64_t> &ciphertextData) const {
+  std::vector<std::vector<int64_t>> all;
+  decryptCiphertextBatch(abstractCiphertext, all);
+  ciphertextData = std::move(all[0]);
 }
 
 std::string HipCiphertextFactory::getString(AbstractCiphertext &abstractCiphertext) const {

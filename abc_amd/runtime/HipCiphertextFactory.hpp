@@ -5,6 +5,7 @@
 // relinearisation / all default Galois keys (:89-93), pad-with-last-value (:102-115).
 #pragma once
 
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -17,6 +18,11 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
   abc_hip_ctx *ctx = nullptr;  // owned: device tables + keys
   int limbs = 0;               // data limbs L
   uint64_t keySeed = 0;
+  // Batch mode (an extension the reference lacks; it evaluates one circuit at a time, RuntimeVisitor.h:34): every
+  // ciphertext of this factory is B independent ciphertexts that all operations process in one batched device call, so
+  // ONE pass of an unchanged interpreter (ABC's RuntimeVisitor or CircuitRuntime) evaluates the circuit on B input sets.
+  size_t batch = 1;
+  mutable std::deque<std::vector<std::vector<int64_t>>> queuedInputs;
 
   void setupContext(int device);
   template <typename T>
@@ -24,7 +30,7 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
 
  public:
   HipCiphertextFactory();
-  explicit HipCiphertextFactory(unsigned int numElementsPerCiphertextSlot, int device = 0, uint64_t seed = 0);
+  explicit HipCiphertextFactory(unsigned int numElementsPerCiphertextSlot, int device = 0, uint64_t seed = 0, size_t batchSize = 1);
   virtual ~HipCiphertextFactory();  // (ABC's AbstractCiphertextFactory declares no virtual destructor)
   HipCiphertextFactory(const HipCiphertextFactory &) = delete;  // one device context per factory
   HipCiphertextFactory &operator=(const HipCiphertextFactory &) = delete;
@@ -32,7 +38,14 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
   [[nodiscard]] abc_hip_ctx *context() const { return ctx; }
   [[nodiscard]] unsigned int getCiphertextSlotSize() const { return ciphertextSlotSize; }
   [[nodiscard]] int dataLimbs() const { return limbs; }
-  [[nodiscard]] size_t ciphertextWords() const { return (size_t)2 * limbs * ciphertextSlotSize; }
+  [[nodiscard]] size_t batchSize() const { return batch; }
+  [[nodiscard]] size_t ciphertextWords() const { return batch * 2 * limbs * ciphertextSlotSize; }  // of one (batched) value
+
+  // Batch mode: the next createCiphertext call encrypts these B vectors (one per circuit instance) instead of B copies
+  // of its argument; calls are served in queue order, i.e. in the order the interpreter declares its secret inputs.
+  void queueBatchedInput(std::vector<std::vector<int64_t>> perInstance) const;
+  // all B decrypted slot vectors of a batched ciphertext (decryptCiphertext returns instance 0, the reference's view)
+  void decryptCiphertextBatch(AbstractCiphertext &abstractCiphertext, std::vector<std::vector<int64_t>> &out) const;
 
   // device plaintext [N] (coefficients mod t) from public values; caller frees with freeDevice
   uint64_t *createPlaintext(const std::vector<int> &value) const;

@@ -150,5 +150,43 @@ int main() {
     EXPECT_THROWS(rt.executeAst("secret int r = rotate(__input0__ +++ __input0__, 2);"));
     EXPECT_THROWS(rt.executeAst("secret int r = rotate(__input0__, 5000);"));
   });
+  // ---- batch mode: one pass of the unchanged interpreter evaluates the circuit on B independent input sets ----
+  t.run("batch mode: 5 circuit instances in one interpreter pass", [&] {
+    const size_t B = 5;
+    HipCiphertextFactory fb(N, 0, 0xABC00002ull, B);
+    std::vector<std::vector<int64_t>> x(B), y(B);
+    for (size_t b = 0; b < B; ++b)
+      for (int i = 0; i < 12; ++i) {
+        x[b].push_back((int64_t)(7 * b + 3 * i + 1) % 40);
+        y[b].push_back((int64_t)(5 * b + i * i + 2) % 40);
+      }
+    fb.queueBatchedInput(x);  // consumed by the declaration of __input0__
+    fb.queueBatchedInput(y);  // ... of __input1__
+    CircuitRuntime rt(fb, "secret int __input0__ = {0}; secret int __input1__ = {0}; int __input2__ = {2, 3, 4, 5, 6, 7, 8, 9, 1, 2, 3, 4};");
+    rt.executeAst("secret int p = __input0__ *** __input1__; secret int r = rotate(p, 2); "
+                  "secret int result = (r +++ __input0__) --- __input2__; return result;");  // one ct x ct level: N = 4096
+    auto out = rt.getOutput("y = result;");
+    std::vector<std::vector<int64_t>> got;
+    for (auto &pr : out)
+      if (pr.first == "y") fb.decryptCiphertextBatch(*dynamic_cast<AbstractCiphertext *>(pr.second.get()), got);
+    EXPECT_TRUE(got.size() == B);
+    const std::vector<int64_t> pub = {2, 3, 4, 5, 6, 7, 8, 9, 1, 2, 3, 4};
+    for (size_t b = 0; b < B; ++b) {
+      // slots are padded with the last value, rotate(p, 2) brings slot i+2 to slot i
+      auto at = [&](const std::vector<int64_t> &v, size_t i) { return i < v.size() ? v[i] : v.back(); };
+      for (size_t i = 0; i < 10; ++i) {
+        const int64_t want = at(x[b], i + 2) * at(y[b], i + 2) + at(x[b], i) - pub[i];
+        if (got[b][i] != want)
+          throw std::runtime_error("instance " + std::to_string(b) + " slot " + std::to_string(i) + ": got " +
+                                   std::to_string(got[b][i]) + " want " + std::to_string(want));
+      }
+    }
+    // the reference's single-result view is instance 0
+    std::vector<int64_t> first;
+    for (auto &pr : out)
+      if (pr.first == "y") fb.decryptCiphertext(*dynamic_cast<AbstractCiphertext *>(pr.second.get()), first);
+    EXPECT_TRUE(first == got[0]);
+    EXPECT_THROWS(fb.queueBatchedInput(std::vector<std::vector<int64_t>>(B + 1, std::vector<int64_t>{1})));
+  });
   return t.summary();
 }
