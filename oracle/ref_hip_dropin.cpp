@@ -78,6 +78,48 @@ int main() {
   runCase(factory, "secret declaration inside the program", "",
           "secret int sum = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10}; return sum;", "y = sum;", {},
           {{"y", {1, 2, 3, 4, 5, 6, 7, 8, 9, 10}}});
+  // batch mode: the reference's interpreter, unchanged, evaluates testBinaryExpressionCtxtCtxt on four input sets at once
+  try {
+    const size_t B = 4;
+    HipCiphertextFactory batched(4096, 0, 0xABC00004ull, B);
+    std::vector<std::vector<int64_t>> x(B), y(B);
+    for (size_t b = 0; b < B; ++b)
+      for (int i = 0; i < 10; ++i) {
+        x[b].push_back((int64_t)(11 * b + 5 * i + 3) % 97);
+        y[b].push_back((int64_t)(7 * b + i * i + 1) % 89);
+      }
+    batched.queueBatchedInput(x);
+    batched.queueBatchedInput(y);
+    auto astInput = Parser::parse(std::string("secret int __input0__ = {0}; secret int __input1__ = {0};"));
+    auto astProgram = Parser::parse(std::string("secret int result = __input0__ *** __input1__; return result;"));
+    auto astOutput = Parser::parse(std::string("y = result;"));
+    TypeCheckingVisitor tcv;
+    auto rootScope = std::make_unique<Scope>(*astProgram);
+    for (const std::string id : {"__input0__", "__input1__"}) {
+      auto scoped = std::make_unique<ScopedIdentifier>(*rootScope, id);
+      rootScope->addIdentifier(id);
+      tcv.addVariableDatatype(*scoped, Datatype(Type::INT, true));
+    }
+    tcv.setRootScope(std::move(rootScope));
+    astProgram->accept(tcv);
+    auto taint = tcv.getSecretTaintedNodes();
+    RuntimeVisitor rv(batched, *astInput, taint);
+    rv.executeAst(*astProgram);
+    auto result = rv.getOutput(*astOutput);
+    bool ok = result.size() == 1;
+    for (auto &[id, value] : result) {
+      std::vector<std::vector<int64_t>> all;
+      batched.decryptCiphertextBatch(*dynamic_cast<AbstractCiphertext *>(value.get()), all);
+      ok = ok && all.size() == B;
+      for (size_t b = 0; ok && b < B; ++b)
+        for (size_t i = 0; i < 10; ++i) ok = ok && all[b][i] == x[b][i] * y[b][i];
+    }
+    std::cout << (ok ? "[  OK  ] " : "[ FAIL ] ") << "batch mode: four instances in one RuntimeVisitor pass" << std::endl;
+    failures += !ok;
+  } catch (const std::exception &e) {
+    std::cout << "[ FAIL ] batch mode: " << e.what() << std::endl;
+    ++failures;
+  }
   std::cout << (failures ? "FAILED " : "passed ") << "reference RuntimeVisitor over HipCiphertextFactory, failures=" << failures
             << std::endl;
   return failures ? 1 : 0;
