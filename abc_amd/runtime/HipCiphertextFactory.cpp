@@ -78,7 +78,7 @@ std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCiphertext(const
   // B rows of N slots: the queued per-instance vectors if there are any, else B copies of `data`
   std::vector<int64_t> slots;
   slots.reserve(batch * ciphertextSlotSize);
-  if (batch > 1 && !queuedInputs.empty()) {
+  if (!queuedInputs.empty()) {
     for (const auto &row : queuedInputs.front()) {
       const auto e = expandVector(row);
       slots.insert(slots.end(), e.begin(), e.end());
