@@ -522,6 +522,17 @@ int abc_hip_ctx_create(int scheme, int logn, const uint64_t *primes, int nprimes
       rc = 1;
     }
   }
+  if (!rc && !std::getenv("ABC_HIP_SYNC_ALLOC")) {  // stream-ordered allocator where the runtime has one
+    hipMemPool_t pool = nullptr;
+    void *probe = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, c->device) == hipSuccess && pool) {
+      uint64_t keep = ~0ull;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      if (hipMallocAsync(&probe, 256, c->stream) == hipSuccess && hipFreeAsync(probe, c->stream) == hipSuccess)
+        c->async_alloc = true;
+    }
+    (void)hipGetLastError();
+  }
   if (rc) { abc_hip_ctx_destroy(c); return 1; }
   *out = c;
   return 0;
@@ -572,15 +583,28 @@ int abc_hip_sync(abc_hip_ctx *c) {
   return 0;
 }
 
+// Stream-ordered allocation from the device's memory pool (kept resident: release threshold = max): a ciphertext
+// buffer is handed out and taken back in microseconds without synchronising the device, which matters to the plugin
+// classes -- the interpreter clones a ciphertext on every variable read.  Every use of a buffer is ordered on the
+// context's stream (the internal lanes fork from and join it inside each call), so is its release.
 int abc_hip_malloc(abc_hip_ctx *c, void **d_ptr, size_t bytes) {
   CTX_GUARD(c);
-  ABC_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
+  if (c->async_alloc) {
+    ABC_HIP_CHECK(hipMallocAsync(d_ptr, bytes ? bytes : 8, c->stream));
+  } else {
+    ABC_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
+  }
   return 0;
 }
 int abc_hip_free(abc_hip_ctx *c, void *d_ptr) {
   CTX_GUARD(c);
-  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
-  ABC_HIP_CHECK(hipFree(d_ptr));
+  if (!d_ptr) return 0;
+  if (c->async_alloc) {
+    ABC_HIP_CHECK(hipFreeAsync(d_ptr, c->stream));
+  } else {
+    ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+    ABC_HIP_CHECK(hipFree(d_ptr));
+  }
   return 0;
 }
 int abc_hip_memcpy_h2d(abc_hip_ctx *c, void *d, const void *h, size_t bytes) {

@@ -117,6 +117,7 @@ struct abc_hip_ctx {
   abc::Mod *d_mods = nullptr;
   uint64_t *d_tw = nullptr;
   double *d_ftw = nullptr;
+  bool async_alloc = false;  // abc_hip_malloc / abc_hip_free are stream-ordered (hipMallocAsync)
   bool use_fp = true;  // fp64 transforms for primes < 2^50 (ABC_HIP_NO_FP64=1 forces the integer path)
   abc::DevConst *d_cst = nullptr;
   uint32_t *d_slot_map = nullptr;
