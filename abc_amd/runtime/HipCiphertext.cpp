@@ -24,29 +24,25 @@ struct DevicePlain {  // RAII for the per-call plaintext the reference also re-e
 };
 }  // namespace
 
-HipCiphertext::HipCiphertext(const std::reference_wrapper<const HipCiphertextFactory> hipFactory)
-    : AbstractCiphertext((const std::reference_wrapper<const AbstractCiphertextFactory>)hipFactory) {
+HipCiphertext::Buffer::~Buffer() {
+  if (p) abc_hip_free(f.context(), p);  // stream-ordered: every use of the buffer was issued before this point
+}
+
+std::shared_ptr<HipCiphertext::Buffer> HipCiphertext::allocate(const HipCiphertextFactory &f) {
   void *p = nullptr;
-  abcHipCheck(abc_hip_malloc(hipFactory.get().context(), &p, hipFactory.get().ciphertextWords() * 8), "ciphertext allocation");
-  d_data = static_cast<uint64_t *>(p);
+  abcHipCheck(abc_hip_malloc(f.context(), &p, f.ciphertextWords() * 8), "ciphertext allocation");
+  return std::make_shared<Buffer>(f, static_cast<uint64_t *>(p));
 }
 
-HipCiphertext::~HipCiphertext() { release(); }
+HipCiphertext::HipCiphertext(const std::reference_wrapper<const HipCiphertextFactory> hipFactory)
+    : AbstractCiphertext((const std::reference_wrapper<const AbstractCiphertextFactory>)hipFactory), buf(allocate(hipFactory.get())) {}
 
-void HipCiphertext::release() noexcept {
-  if (!d_data) return;
-  if (auto f = dynamic_cast<const HipCiphertextFactory *>(&factory.get())) abc_hip_free(f->context(), d_data);
-  d_data = nullptr;
-}
+HipCiphertext::~HipCiphertext() = default;
 
-HipCiphertext::HipCiphertext(const HipCiphertext &other) : HipCiphertext(std::cref(other.getFactory())) {
-  // deep copy: the interpreter clones on every variable read (src/runtime/RuntimeVisitor.cpp:431-437)
-  abcHipCheck(abc_hip_memcpy_d2d(getFactory().context(), d_data, other.d_data, getFactory().ciphertextWords() * 8), "clone");
-}
+// "deep copy" by value semantics: shares the buffer until one side writes
+HipCiphertext::HipCiphertext(const HipCiphertext &other) : AbstractCiphertext(other.factory), buf(other.buf) {}
 
-HipCiphertext::HipCiphertext(HipCiphertext &&other) noexcept : AbstractCiphertext(other.factory), d_data(other.d_data) {
-  other.d_data = nullptr;
-}
+HipCiphertext::HipCiphertext(HipCiphertext &&other) noexcept : AbstractCiphertext(other.factory), buf(std::move(other.buf)) {}
 
 HipCiphertext &HipCiphertext::operator=(const HipCiphertext &other) { return *this = HipCiphertext(other); }
 
@@ -54,10 +50,21 @@ HipCiphertext &HipCiphertext::operator=(HipCiphertext &&other) {
   if (&other == this) return *this;
   if (&factory.get() != &other.factory.get())
     throw std::runtime_error("Cannot move Ciphertext from factory A into Ciphertext created by Factory B.");
-  release();
-  d_data = other.d_data;
-  other.d_data = nullptr;
+  buf = std::move(other.buf);
   return *this;
+}
+
+std::shared_ptr<HipCiphertext::Buffer> HipCiphertext::target() const {
+  return buf.use_count() == 1 ? buf : allocate(getFactory());
+}
+
+uint64_t *HipCiphertext::devicePtr() {
+  if (buf.use_count() != 1) {  // a writer gets its own copy
+    auto t = allocate(getFactory());
+    abcHipCheck(abc_hip_memcpy_d2d(getFactory().context(), t->p, buf->p, getFactory().ciphertextWords() * 8), "clone");
+    buf = std::move(t);
+  }
+  return buf->p;
 }
 
 const HipCiphertextFactory &HipCiphertext::getFactory() const {
@@ -76,40 +83,48 @@ int HipCiphertext::noiseBits() const {
 // ---- ctxt-ctxt ----
 std::unique_ptr<AbstractCiphertext> HipCiphertext::add(const AbstractCiphertext &operand) const {
   auto r = fresh();
-  abcHipCheck(abc_hip_add(getFactory().context(), d_data, cast(operand).d_data, r->d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "add");
+  abcHipCheck(abc_hip_add(getFactory().context(), in(), cast(operand).in(), r->buf->p, 2, getFactory().dataLimbs(), getFactory().batchSize()), "add");
   return r;
 }
 std::unique_ptr<AbstractCiphertext> HipCiphertext::subtract(const AbstractCiphertext &operand) const {
   auto r = fresh();
-  abcHipCheck(abc_hip_sub(getFactory().context(), d_data, cast(operand).d_data, r->d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "sub");
+  abcHipCheck(abc_hip_sub(getFactory().context(), in(), cast(operand).in(), r->buf->p, 2, getFactory().dataLimbs(), getFactory().batchSize()), "sub");
   return r;
 }
 std::unique_ptr<AbstractCiphertext> HipCiphertext::multiply(const AbstractCiphertext &operand) const {
   // Evaluator::multiply + relinearize_inplace, src/runtime/SealCiphertext.cpp:102-107
   auto r = fresh();
-  abcHipCheck(abc_hip_mul_relin(getFactory().context(), d_data, cast(operand).d_data, r->d_data, getFactory().dataLimbs(), getFactory().batchSize()),
+  abcHipCheck(abc_hip_mul_relin(getFactory().context(), in(), cast(operand).in(), r->buf->p, getFactory().dataLimbs(), getFactory().batchSize()),
               "multiply");
   return r;
 }
 void HipCiphertext::addInplace(const AbstractCiphertext &operand) {
-  abcHipCheck(abc_hip_add(getFactory().context(), d_data, cast(operand).d_data, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "add");
+  auto t = target();
+  abcHipCheck(abc_hip_add(getFactory().context(), in(), cast(operand).in(), t->p, 2, getFactory().dataLimbs(), getFactory().batchSize()), "add");
+  adopt(std::move(t));
 }
 void HipCiphertext::subtractInplace(const AbstractCiphertext &operand) {
-  abcHipCheck(abc_hip_sub(getFactory().context(), d_data, cast(operand).d_data, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "sub");
+  auto t = target();
+  abcHipCheck(abc_hip_sub(getFactory().context(), in(), cast(operand).in(), t->p, 2, getFactory().dataLimbs(), getFactory().batchSize()), "sub");
+  adopt(std::move(t));
 }
 void HipCiphertext::multiplyInplace(const AbstractCiphertext &operand) {
-  abcHipCheck(abc_hip_mul_relin(getFactory().context(), d_data, cast(operand).d_data, d_data, getFactory().dataLimbs(), getFactory().batchSize()),
+  auto t = target();
+  abcHipCheck(abc_hip_mul_relin(getFactory().context(), in(), cast(operand).in(), t->p, getFactory().dataLimbs(), getFactory().batchSize()),
               "multiply");
+  adopt(std::move(t));
 }
 
 // ---- rotation ----
 std::unique_ptr<AbstractCiphertext> HipCiphertext::rotateRows(int steps) const {
   auto r = fresh();
-  abcHipCheck(abc_hip_rotate(getFactory().context(), d_data, r->d_data, getFactory().dataLimbs(), steps, getFactory().batchSize()), "rotate_rows");
+  abcHipCheck(abc_hip_rotate(getFactory().context(), in(), r->buf->p, getFactory().dataLimbs(), steps, getFactory().batchSize()), "rotate_rows");
   return r;
 }
 void HipCiphertext::rotateRowsInplace(int steps) {
-  abcHipCheck(abc_hip_rotate(getFactory().context(), d_data, d_data, getFactory().dataLimbs(), steps, getFactory().batchSize()), "rotate_rows");
+  auto t = target();
+  abcHipCheck(abc_hip_rotate(getFactory().context(), in(), t->p, getFactory().dataLimbs(), steps, getFactory().batchSize()), "rotate_rows");
+  adopt(std::move(t));
 }
 
 // ---- ctxt-plain ----
@@ -130,22 +145,30 @@ std::unique_ptr<AbstractCiphertext> HipCiphertext::multiplyPlain(const ICleartex
 }
 void HipCiphertext::addPlainInplace(const ICleartext &operand) {
   DevicePlain pl(getFactory(), intCleartext(operand, "ADD").getData());
-  abcHipCheck(abc_hip_add_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "add_plain");
+  auto t = target();
+  abcHipCheck(abc_hip_add_plain(getFactory().context(), in(), pl.p, 0, t->p, 2, getFactory().dataLimbs(), getFactory().batchSize()), "add_plain");
+  adopt(std::move(t));
 }
 void HipCiphertext::subtractPlainInplace(const ICleartext &operand) {
   DevicePlain pl(getFactory(), intCleartext(operand, "SUB").getData());
-  abcHipCheck(abc_hip_sub_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "sub_plain");
+  auto t = target();
+  abcHipCheck(abc_hip_sub_plain(getFactory().context(), in(), pl.p, 0, t->p, 2, getFactory().dataLimbs(), getFactory().batchSize()), "sub_plain");
+  adopt(std::move(t));
 }
 void HipCiphertext::multiplyPlainInplace(const ICleartext &operand) {
   const auto &ct = intCleartext(operand, "MULTIPLY");
   if (ct.allEqual(-1)) {  // negation shortcut, src/runtime/SealCiphertext.cpp:192-193
-    abcHipCheck(abc_hip_negate(getFactory().context(), d_data, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()), "negate");
+    auto t = target();
+    abcHipCheck(abc_hip_negate(getFactory().context(), in(), t->p, 2, getFactory().dataLimbs(), getFactory().batchSize()), "negate");
+    adopt(std::move(t));
     return;
   }
   DevicePlain pl(getFactory(), ct.getData());
   // multiply_plain keeps size 2, so the reference's relinearize_inplace (:197) is a no-op
-  abcHipCheck(abc_hip_multiply_plain(getFactory().context(), d_data, pl.p, 0, d_data, 2, getFactory().dataLimbs(), getFactory().batchSize()),
+  auto t = target();
+  abcHipCheck(abc_hip_multiply_plain(getFactory().context(), in(), pl.p, 0, t->p, 2, getFactory().dataLimbs(), getFactory().batchSize()),
               "multiply_plain");
+  adopt(std::move(t));
 }
 
 // ---- AbstractValue dispatch (src/runtime/SealCiphertext.cpp:208-239) ----

@@ -6,16 +6,36 @@
 // ciphertext, non-owning reference to the factory, cross-factory move-assign throws, :25-34).
 #pragma once
 
+#include <memory>
+
 #include "plugin_api.hpp"
 
 #include "HipCiphertextFactory.hpp"
 
 class HipCiphertext : public AbstractCiphertext {
-  uint64_t *d_data = nullptr;  // device buffer [B][2][L][N] (B = the factory's batch size, 1 by default); owned
+  // Device buffer [B][2][L][N] (B = the factory's batch size, 1 by default), shared copy-on-write: clone() and the
+  // copy constructor only take another reference (the interpreter clones on EVERY variable read,
+  // src/runtime/RuntimeVisitor.cpp:431-437, and most clones are only ever read), and an in-place operation on a shared
+  // buffer computes out of place into a fresh one -- every C-ABI operation takes separate input and output pointers --
+  // so value semantics hold without a single device-to-device copy.
+  struct Buffer {
+    const HipCiphertextFactory &f;
+    uint64_t *p;
+    Buffer(const HipCiphertextFactory &fac, uint64_t *ptr) : f(fac), p(ptr) {}
+    ~Buffer();
+    Buffer(const Buffer &) = delete;
+    Buffer &operator=(const Buffer &) = delete;
+  };
+  std::shared_ptr<Buffer> buf;
 
+  static std::shared_ptr<Buffer> allocate(const HipCiphertextFactory &f);
   std::unique_ptr<HipCiphertext> clone_impl() const;
   std::unique_ptr<HipCiphertext> fresh() const;
-  void release() noexcept;
+  uint64_t *in() const { return buf->p; }
+  // destination of an in-place operation: the own buffer if nobody shares it, otherwise a fresh one, which `adopt`
+  // installs after the operation has been issued
+  std::shared_ptr<Buffer> target() const;
+  void adopt(std::shared_ptr<Buffer> t) { buf = std::move(t); }
 
  public:
   ~HipCiphertext() override;
@@ -25,8 +45,8 @@ class HipCiphertext : public AbstractCiphertext {
   HipCiphertext &operator=(const HipCiphertext &other);
   HipCiphertext &operator=(HipCiphertext &&other);
 
-  [[nodiscard]] const uint64_t *devicePtr() const { return d_data; }
-  [[nodiscard]] uint64_t *devicePtr() { return d_data; }
+  [[nodiscard]] const uint64_t *devicePtr() const { return buf->p; }
+  [[nodiscard]] uint64_t *devicePtr();  // for writing: un-shares first
   [[nodiscard]] const HipCiphertextFactory &getFactory() const override;
   [[nodiscard]] int noiseBits() const;  // SealCiphertext::noiseBits, SealCiphertext.cpp:80-83 (host-side diagnostic)
 

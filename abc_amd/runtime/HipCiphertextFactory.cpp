@@ -128,7 +128,8 @@ void HipCiphertextFactory::decryptCiphertextBatch(AbstractCiphertext &abstractCi
   void *d_plain = nullptr, *d_vals = nullptr;
   abcHipCheck(abc_hip_malloc(ctx, &d_plain, bytes), "decrypt allocation");
   if (abc_hip_malloc(ctx, &d_vals, bytes)) { abc_hip_free(ctx, d_plain); abcHipCheck(1, "decrypt allocation"); }
-  int rc = abc_hip_decrypt(ctx, ctxt.devicePtr(), 2, limbs, static_cast<uint64_t *>(d_plain), batch);
+  int rc = abc_hip_decrypt(ctx, static_cast<const HipCiphertext &>(ctxt).devicePtr(), 2, limbs, static_cast<uint64_t *>(d_plain),
+                           batch);  // read-only access: does not un-share a copy-on-write buffer
   if (!rc) rc = abc_hip_batch_decode(ctx, static_cast<const uint64_t *>(d_plain), static_cast<int64_t *>(d_vals), batch);
   std::vector<int64_t> flat(words);
   if (!rc) rc = abc_hip_memcpy_d2h(ctx, flat.data(), d_vals, bytes);  // synchronises: result observable on return
