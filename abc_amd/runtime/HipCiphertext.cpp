@@ -16,11 +16,9 @@ const Cleartext<int> &intCleartext(const ICleartext &operand, const char *op) {
   if (auto p = dynamic_cast<const Cleartext<int> *>(&operand)) return *p;
   throw std::runtime_error(std::string(op) + "(Ciphertext,Cleartext) requires a Cleartext<int> as BFV supports integers only.");
 }
-struct DevicePlain {  // RAII for the per-call plaintext the reference also re-encodes on every plain op
-  const HipCiphertextFactory &f;
-  uint64_t *p;
-  DevicePlain(const HipCiphertextFactory &fac, const std::vector<int> &v) : f(fac), p(fac.createPlaintext(v)) {}
-  ~DevicePlain() { f.freeDevice(p); }
+struct DevicePlain {  // encoded plain operand, from the factory's cache (the reference re-encodes it on every plain op)
+  const uint64_t *p;
+  DevicePlain(const HipCiphertextFactory &fac, const std::vector<int> &v) : p(fac.cachedPlaintext(v)) {}
 };
 }  // namespace
 

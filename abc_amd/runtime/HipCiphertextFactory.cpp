@@ -21,7 +21,22 @@ void HipCiphertextFactory::queueBatchedInput(std::vector<std::vector<int64_t>> p
   queuedInputs.push_back(std::move(perInstance));
 }
 
-HipCiphertextFactory::~HipCiphertextFactory() { abc_hip_ctx_destroy(ctx); }
+HipCiphertextFactory::~HipCiphertextFactory() {
+  for (auto &e : plainCache) abc_hip_free(ctx, e.d_plain);
+  abc_hip_ctx_destroy(ctx);
+}
+
+const uint64_t *HipCiphertextFactory::cachedPlaintext(const std::vector<int> &value) const {
+  const std::vector<int64_t> key(value.begin(), value.end());
+  for (const auto &e : plainCache)
+    if (e.values == key) return e.d_plain;
+  if (plainCache.size() >= kPlainCacheEntries) {
+    abc_hip_free(ctx, plainCache.front().d_plain);
+    plainCache.pop_front();
+  }
+  plainCache.push_back(CachedPlain{key, createPlaintext(key)});
+  return plainCache.back().d_plain;
+}
 
 void HipCiphertextFactory::setupContext(int device) {
   // same parameter choice as SealCiphertextFactory::setupSealContext (SealCiphertextFactory.cpp:72-100)

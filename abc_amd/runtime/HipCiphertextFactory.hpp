@@ -23,6 +23,14 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
   // ONE pass of an unchanged interpreter (ABC's RuntimeVisitor or CircuitRuntime) evaluates the circuit on B input sets.
   size_t batch = 1;
   mutable std::deque<std::vector<std::vector<int64_t>>> queuedInputs;
+  // Encoded plaintexts of recent plain operands (the reference re-encodes its operand on every plain operation,
+  // SealCiphertext.cpp:132,143,154: here a repeated constant costs one encode + upload, and no device synchronisation)
+  struct CachedPlain {
+    std::vector<int64_t> values;
+    uint64_t *d_plain;
+  };
+  mutable std::deque<CachedPlain> plainCache;
+  static constexpr size_t kPlainCacheEntries = 32;
 
   void setupContext(int device);
   template <typename T>
@@ -52,6 +60,9 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
   uint64_t *createPlaintext(const std::vector<int64_t> &value) const;
   uint64_t *createPlaintext(int64_t value) const;
   void freeDevice(void *p) const;
+  // same, owned by the factory's cache: valid until kPlainCacheEntries further distinct operands have been encoded
+  // (release is stream-ordered, so operations already issued on an evicted plaintext stay correct)
+  const uint64_t *cachedPlaintext(const std::vector<int> &value) const;
 
   std::unique_ptr<AbstractCiphertext> createCiphertext(const std::vector<int64_t> &data) const override;
   std::unique_ptr<AbstractCiphertext> createCiphertext(const std::vector<int> &data) const override;
