@@ -58,6 +58,17 @@ __device__ __forceinline__ u64 dot_shoup_lazy(int n, FA a, FW w, FS ws, const Mo
 // lazy value of dot_shoup_lazy -> [0, q)
 __device__ __forceinline__ u64 canon_dot(u64 v, const Mod &m) { return m.bits > 58 ? csub(v, m.q) : reduce64(v, m); }
 
+// Constant rows of the conversion matrices, fetched only once the previous outer iteration's result exists.  The fully
+// unrolled BEHZ kernels are one basic block; left alone, the compiler hoists EVERY iteration's scalar constant loads to
+// the top, 104 SGPRs cannot hold an 8 x 9 matrix with its Shoup quotients, and the spill code (v_writelane / v_readlane)
+// was 45 % of the floor kernel's instructions.  The empty asm makes the row pointer depend on `dep` (a VGPR result of
+// the previous iteration), so each iteration's loads stay in their iteration.
+template <class T>
+__device__ __forceinline__ const ABC_CONST_AS T *row_after(const ABC_CONST_AS T *p, u64 dep) {
+  asm volatile("" : "+s"(p) : "v"(dep));
+  return p;
+}
+
 // ---- BEHZ steps (1)-(2): q -> Bsk with Montgomery reduction of the q-overflow ----
 // in: [polys][L][N] coefficient form; out: [polys][nBsk][N]
 // LT > 0: limb counts known at compile time (L = LT, nBsk = NBT + 1), so every loop unrolls and the conversion
@@ -85,15 +96,18 @@ __global__ __launch_bounds__(256) void k_behz_extend(DevCtx c, const u64 *in, co
       mt += (u32)v * (u32)k.q_to_mtilde[i];  // arithmetic mod 2^32
     }
     const u32 r32 = mt * (u32)k.neg_inv_q_mod_mtilde;
+    u64 dep = tmp[L - 1];
 #pragma unroll
     for (int j = 0; j < nBsk; j++) {
       const Mod m = mod_at(c, c.id_bsk + j);
-      const u64 conv = dot_shoup_lazy(L, [&](int i) { return tmp[i]; }, [&](int i) { return k.q_to_bsk[j][i]; },
-                                      [&](int i) { return k.q_to_bsk_s[j][i]; }, m);  // < 2p
+      const ABC_CONST_AS u64 *row = row_after(&k.q_to_bsk[j][0], dep), *row_s = row_after(&k.q_to_bsk_s[j][0], dep);
+      const u64 conv = dot_shoup_lazy(L, [&](int i) { return tmp[i]; }, [&](int i) { return row[i]; },
+                                      [&](int i) { return row_s[i]; }, m);  // < 2p
       u64 r = r32;
       if (r32 >= 0x80000000u) r += m.q - 0x100000000ull;  // centred representative of r mod m~
       const u64 v = conv + mul_shoup_lazy(r, k.q_mod_bsk[j], k.q_mod_bsk_s[j], m.q);  // < 4p < 2^64
-      out[(p * nBsk + j) * c.n + x] = mul_shoup(v, k.inv_mtilde_mod_bsk[j], k.inv_mtilde_mod_bsk_s[j], m.q);
+      dep = mul_shoup(v, k.inv_mtilde_mod_bsk[j], k.inv_mtilde_mod_bsk_s[j], m.q);
+      out[(p * nBsk + j) * c.n + x] = dep;
     }
   }
 }
@@ -133,14 +147,17 @@ __global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, con
       // * t * (q/q_i)^-1; canonical: the conversion below sums these residues as INTEGERS in [0, q_i)
       tq[i] = mul_shoup(dq[(p * L + i) * c.n + x], k.flr_q[i], k.flr_q_s[i], mod_at(c, i).q);
     }
+    u64 dep = tq[L - 1];
 #pragma unroll
     for (int j = 0; j < nBsk; j++) {
       const Mod m = mod_at(c, c.id_bsk + j);
-      const u64 conv = dot_shoup_lazy(L, [&](int i) { return tq[i]; }, [&](int i) { return k.q_to_bsk[j][i]; },
-                                      [&](int i) { return k.q_to_bsk_s[j][i]; }, m);
+      const ABC_CONST_AS u64 *row = row_after(&k.q_to_bsk[j][0], dep), *row_s = row_after(&k.q_to_bsk_s[j][0], dep);
+      const u64 conv = dot_shoup_lazy(L, [&](int i) { return tq[i]; }, [&](int i) { return row[i]; },
+                                      [&](int i) { return row_s[i]; }, m);
       // (dB*t - conv) * q^-1 = dB*(t q^-1) - conv*q^-1   (both constants carry Shoup quotients)
       const u64 xb = mul_shoup(dB[(p * nBsk + j) * c.n + x], k.tinvq_bsk[j], k.tinvq_bsk_s[j], m.q);
       fl[j] = sub_mod(xb, mul_shoup(conv, k.inv_q_mod_bsk[j], k.inv_q_mod_bsk_s[j], m.q), m.q);
+      dep = fl[j];
     }
     u64 tb[LT ? NBT : kMaxLimbs];
 #pragma unroll
@@ -149,16 +166,19 @@ __global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, con
                                                   [&](int b2) { return k.B_to_msk_s[b2]; }, msk), msk);
     const u64 alpha = mul_shoup(sub_mod(msk_conv, fl[nB], msk.q), k.inv_B_mod_msk, k.inv_B_mod_msk_s, msk.q);
     const bool neg = alpha > (msk.q >> 1);
+    dep = alpha;
 #pragma unroll
     for (int i = 0; i < L; i++) {
       const Mod m = mod_at(c, i);
-      u64 v = dot_shoup_lazy(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_q[i][b2]; },
-                             [&](int b2) { return k.B_to_q_s[i][b2]; }, m);
+      const ABC_CONST_AS u64 *row = row_after(&k.B_to_q[i][0], dep), *row_s = row_after(&k.B_to_q_s[i][0], dep);
+      u64 v = dot_shoup_lazy(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return row[b2]; },
+                             [&](int b2) { return row_s[b2]; }, m);
       // +- alpha * B: one more lazy term (the subtraction as 2q - term keeps the sum non-negative)
       const u64 ab = mul_shoup_lazy(neg ? msk.q - alpha : alpha, k.B_mod_q[i], k.B_mod_q_s[i], m.q);
       v = neg ? v + ab : v + m.two_q - ab;
       if (m.bits > 58) v = csub(v, m.two_q);  // v < 2q + 2q there
-      out[(p * L + i) * c.n + x] = canon_dot(v, m);
+      dep = canon_dot(v, m);
+      out[(p * L + i) * c.n + x] = dep;
     }
   }
 }
