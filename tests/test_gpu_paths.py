@@ -18,6 +18,7 @@ VARIANTS = {
     "fp64_separate_kernels": {"ABC_HIP_NO_SPLIT": "1", "ABC_HIP_NO_TENSOR_DECOMP": "1"},
     "fp64_split_serial_tail": {"ABC_HIP_TAILMAC_SERIAL": "1"},
     "generic": {"ABC_HIP_NO_FUSED": "1"},
+    "no_galois_fusion_sync_alloc": {"ABC_HIP_NO_GALOIS_FUSION": "1", "ABC_HIP_SYNC_ALLOC": "1"},
 }
 
 
