@@ -522,16 +522,10 @@ int abc_hip_ctx_create(int scheme, int logn, const uint64_t *primes, int nprimes
       rc = 1;
     }
   }
-  if (!rc && !std::getenv("ABC_HIP_SYNC_ALLOC")) {  // stream-ordered allocator where the runtime has one
-    hipMemPool_t pool = nullptr;
-    void *probe = nullptr;
-    if (hipDeviceGetDefaultMemPool(&pool, c->device) == hipSuccess && pool) {
-      uint64_t keep = ~0ull;
-      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-      if (hipMallocAsync(&probe, 256, c->stream) == hipSuccess && hipFreeAsync(probe, c->stream) == hipSuccess)
-        c->async_alloc = true;
-    }
-    (void)hipGetLastError();
+  if (!rc && !std::getenv("ABC_HIP_SYNC_ALLOC")) {
+    c->cache_alloc = true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c->cache_cap = total_b / 4;  // at most a quarter of the device
   }
   if (rc) { abc_hip_ctx_destroy(c); return 1; }
   *out = c;
@@ -547,6 +541,8 @@ void abc_hip_ctx_destroy(abc_hip_ctx *c) {
   for (auto &kv : c->d_galois) (void)hipFree(kv.second);
   (void)hipFree(c->ws);
   for (void *p : c->aux) (void)hipFree(p);
+  for (auto &kv : c->free_blocks)
+    for (void *p : kv.second) (void)hipFree(p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -583,28 +579,43 @@ int abc_hip_sync(abc_hip_ctx *c) {
   return 0;
 }
 
-// Stream-ordered allocation from the device's memory pool (kept resident: release threshold = max): a ciphertext
-// buffer is handed out and taken back in microseconds without synchronising the device, which matters to the plugin
-// classes -- the interpreter clones a ciphertext on every variable read.  Every use of a buffer is ordered on the
-// context's stream (the internal lanes fork from and join it inside each call), so is its release.
+// Caching allocator: a freed buffer goes to a per-context free list (exact-size buckets) instead of back to the
+// driver, and the next request of that size takes it -- no hipMalloc, no hipFree, no device synchronisation.  That is
+// safe because every use of a context's buffers is ordered on the context's stream (the internal lanes fork from and
+// join it inside each call): whatever still runs on a recycled buffer was issued before its new owner's first use.
+// It matters to the plugin classes, where the interpreter clones / drops a ciphertext on every variable read.
+// (hipMallocAsync / hipFreeAsync were tried first and returned wrong results on some boxes of this pool when two
+// contexts alternated; ABC_HIP_SYNC_ALLOC=1 turns the cache off.)
 int abc_hip_malloc(abc_hip_ctx *c, void **d_ptr, size_t bytes) {
   CTX_GUARD(c);
-  if (c->async_alloc) {
-    ABC_HIP_CHECK(hipMallocAsync(d_ptr, bytes ? bytes : 8, c->stream));
-  } else {
-    ABC_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
+  if (!bytes) bytes = 8;
+  if (c->cache_alloc) {
+    auto it = c->free_blocks.find(bytes);
+    if (it != c->free_blocks.end() && !it->second.empty()) {
+      *d_ptr = it->second.back();
+      it->second.pop_back();
+      c->cached_bytes -= bytes;
+      return 0;
+    }
   }
+  ABC_HIP_CHECK(hipMalloc(d_ptr, bytes));
+  if (c->cache_alloc) c->block_size[*d_ptr] = bytes;
   return 0;
 }
 int abc_hip_free(abc_hip_ctx *c, void *d_ptr) {
   CTX_GUARD(c);
   if (!d_ptr) return 0;
-  if (c->async_alloc) {
-    ABC_HIP_CHECK(hipFreeAsync(d_ptr, c->stream));
-  } else {
-    ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
-    ABC_HIP_CHECK(hipFree(d_ptr));
+  if (c->cache_alloc) {
+    auto it = c->block_size.find(d_ptr);
+    if (it != c->block_size.end() && c->cached_bytes + it->second <= c->cache_cap) {
+      c->free_blocks[it->second].push_back(d_ptr);
+      c->cached_bytes += it->second;
+      return 0;
+    }
+    if (it != c->block_size.end()) c->block_size.erase(it);
   }
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  ABC_HIP_CHECK(hipFree(d_ptr));
   return 0;
 }
 int abc_hip_memcpy_h2d(abc_hip_ctx *c, void *d, const void *h, size_t bytes) {

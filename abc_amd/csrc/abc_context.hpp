@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -117,7 +118,11 @@ struct abc_hip_ctx {
   abc::Mod *d_mods = nullptr;
   uint64_t *d_tw = nullptr;
   double *d_ftw = nullptr;
-  bool async_alloc = false;  // abc_hip_malloc / abc_hip_free are stream-ordered (hipMallocAsync)
+  // caching allocator behind abc_hip_malloc / abc_hip_free (abc_context.hip)
+  bool cache_alloc = false;
+  size_t cached_bytes = 0, cache_cap = (size_t)8 << 30;
+  std::unordered_map<size_t, std::vector<void *>> free_blocks;  // size -> cached blocks
+  std::unordered_map<void *, size_t> block_size;                 // every live block handed out by abc_hip_malloc
   bool use_fp = true;  // fp64 transforms for primes < 2^50 (ABC_HIP_NO_FP64=1 forces the integer path)
   abc::DevConst *d_cst = nullptr;
   uint32_t *d_slot_map = nullptr;

@@ -54,9 +54,9 @@ int abc_hip_set_stream(abc_hip_ctx *ctx, void *hip_stream);
 int abc_hip_sync(abc_hip_ctx *ctx);
 
 /* ---- device memory (so that FFI callers need no HIP runtime binding) ----
- * Stream-ordered (hipMallocAsync / hipFreeAsync on the context's stream, pool kept resident): a buffer may be freed
- * right after the last operation on it has been issued, without synchronising; it must only be used with the context
- * that allocated it.  ABC_HIP_SYNC_ALLOC=1 selects plain hipMalloc / synchronise + hipFree. */
+ * Freed buffers are cached per context and recycled by size, so a buffer may be freed right after the last operation
+ * on it has been issued, without synchronising; it must only be used with the context that allocated it.
+ * ABC_HIP_SYNC_ALLOC=1 selects plain hipMalloc / synchronise + hipFree. */
 int abc_hip_malloc(abc_hip_ctx *ctx, void **d_ptr, size_t bytes);
 int abc_hip_free(abc_hip_ctx *ctx, void *d_ptr);
 int abc_hip_memcpy_h2d(abc_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
