@@ -331,6 +331,23 @@ __global__ __launch_bounds__(1024) void k_mb_ntt_stagger(DevCtx c, u64 *data, in
       t, m, 0, 0);
 }
 
+// 4096-point transforms (four workgroups per CU): does a phase offset between co-resident workgroups let one's HBM
+// phases hide under another's arithmetic?  ticks = 0: all start together.
+__global__ __launch_bounds__(256) void k_mb_ntt12(DevCtx c, u64 *data, int mid, int ticks) {
+  __shared__ double lds[lds_words(12)];
+  if (ticks && blockIdx.x < 1024) {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long d = (unsigned long long)((blockIdx.x * 37u) & 255u) * (unsigned)ticks / 256u;
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(8);
+  }
+  const Mod m = mod_at(c, mid);
+  const FpTable t = fp_table(c, mid);
+  u64 *base = data + (size_t)blockIdx.x * 4096;
+  ntt_fwd_block_a<12, FpArith>(
+      lds, [&](int, int i) { return fp_from_u64(base[i]); }, [&](int, int i, double v) { base[i] = fp_to_canon(v, m.qd, m.qinv); },
+      t, m, 2, (int)(blockIdx.x & 3));
+}
+
 // persistent form: 256 x PER workgroups walk the transforms; the next transform's 16 words per lane are fetched into
 // registers before the current one is computed
 template <bool PREFETCH>
@@ -470,6 +487,10 @@ int microbench_ntt(abc_hip_ctx *c, int which, int iters, double *ms) {
       case 10: hipLaunchKernelGGL(k_mb_ntt_stagger, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid, 600); break;
       case 11: hipLaunchKernelGGL(k_mb_ntt_stagger, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid, 1200); break;
       case 12: hipLaunchKernelGGL(k_mb_ntt_stagger, dim3(limbs), dim3(1024), 0, c->stream, c->dc, d, mid, 1700); break;
+      case 13: hipLaunchKernelGGL(k_mb_ntt12, dim3(limbs * 4), dim3(256), 0, c->stream, c->dc, d, mid, 0); break;
+      case 14: hipLaunchKernelGGL(k_mb_ntt12, dim3(limbs * 4), dim3(256), 0, c->stream, c->dc, d, mid, 200); break;
+      case 15: hipLaunchKernelGGL(k_mb_ntt12, dim3(limbs * 4), dim3(256), 0, c->stream, c->dc, d, mid, 430); break;
+      case 16: hipLaunchKernelGGL(k_mb_ntt12, dim3(limbs * 4), dim3(256), 0, c->stream, c->dc, d, mid, 900); break;
       case 5: hipLaunchKernelGGL(k_mb_ntt_persistent<true>, dim3(256), dim3(1024), 0, c->stream, c->dc, d, mid, limbs); break;
       default: set_error("microbench: unknown transform probe"); return 1;
     }

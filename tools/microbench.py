@@ -44,7 +44,9 @@ def main():
                         (304, "ntt_fp_persistent"), (305, "ntt_fp_persistent_prefetch"),
                         (306, "ntt_fp_split_adjacent"), (307, "ntt_fp_split_same_xcd"),
                         (308, "copy_transform_pattern"), (309, "copy_streaming"),
-                        (310, "ntt_fp_stagger_6us"), (311, "ntt_fp_stagger_12us"), (312, "ntt_fp_stagger_17us")):
+                        (310, "ntt_fp_stagger_6us"), (311, "ntt_fp_stagger_12us"), (312, "ntt_fp_stagger_17us"),
+                        (313, "ntt4096x4_no_stagger"), (314, "ntt4096x4_stagger_2us"), (315, "ntt4096x4_stagger_4us"),
+                        (316, "ntt4096x4_stagger_9us")):
         ms = g.microbench(which, 4096)
         res[name] = {"ms": ms, "us_per_transform_per_cu": ms * 1e3 / 4096 * 256}
         print("%-26s %8.3f ms  %6.2f us per transform per CU  (%.0f GB/s if 256 KiB per transform)" %
