@@ -21,7 +21,8 @@ _lib = None
 SYMBOLS = [
     "abc_hip_last_error", "abc_hip_device_count", "abc_hip_ctx_create", "abc_hip_ctx_destroy",
     "abc_hip_default_bfv_primes", "abc_hip_plain_modulus_batching", "abc_hip_create_primes", "abc_hip_ctx_info",
-    "abc_hip_set_stream", "abc_hip_sync", "abc_hip_malloc", "abc_hip_free", "abc_hip_memcpy_h2d", "abc_hip_memcpy_d2h",
+    "abc_hip_set_stream", "abc_hip_sync", "abc_hip_ctx_reload_env", "abc_hip_malloc", "abc_hip_free", "abc_hip_trim",
+    "abc_hip_cached_bytes", "abc_hip_memcpy_h2d", "abc_hip_memcpy_d2h",
     "abc_hip_memcpy_d2d", "abc_hip_keygen", "abc_hip_load_secret_key", "abc_hip_load_public_key",
     "abc_hip_load_relin_key", "abc_hip_load_galois_key", "abc_hip_get_secret_key", "abc_hip_get_public_key",
     "abc_hip_get_relin_key", "abc_hip_get_galois_key", "abc_hip_num_galois_keys", "abc_hip_galois_elt_at",
@@ -54,6 +55,8 @@ def lib():
         L.abc_hip_ctx_create.argtypes = [C.c_int, C.c_int, u64p, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]
         L.abc_hip_ctx_destroy.argtypes = [C.c_void_p]
         L.abc_hip_galois_elt_at.restype = C.c_uint32
+        L.abc_hip_cached_bytes.restype = C.c_size_t
+        L.abc_hip_cached_bytes.argtypes = [C.c_void_p]
         L.abc_hip_galois_elt_from_step.restype = C.c_uint32
         _lib = L
     return _lib
@@ -155,6 +158,15 @@ class Context:
 
     def sync(self):
         _chk(lib().abc_hip_sync(self.h))
+
+    def trim(self):
+        _chk(lib().abc_hip_trim(self.h))
+
+    def cached_bytes(self):
+        return int(lib().abc_hip_cached_bytes(self.h))
+
+    def reload_env(self):
+        _chk(lib().abc_hip_ctx_reload_env(self.h))
 
     def set_stream(self, stream_ptr):
         _chk(lib().abc_hip_set_stream(self.h, C.c_void_p(stream_ptr)))

@@ -19,10 +19,58 @@ namespace abc {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
+static bool env_on(const char *name) {  // set and not "0"
+  const char *e = std::getenv(name);
+  return e && !(e[0] == '0' && e[1] == 0);
+}
+void read_switches(abc_hip_ctx *c) {
+  abc_hip_ctx::Switches s;
+  s.no_fused = env_on("ABC_HIP_NO_FUSED");
+  s.no_split = env_on("ABC_HIP_NO_SPLIT");
+  s.no_split2 = env_on("ABC_HIP_NO_SPLIT2");
+  s.no_tensor_decomp = env_on("ABC_HIP_NO_TENSOR_DECOMP");
+  s.no_tensor_intt = env_on("ABC_HIP_NO_TENSOR_INTT");
+  s.tailmac_serial = env_on("ABC_HIP_TAILMAC_SERIAL");
+  s.no_galois_fusion = env_on("ABC_HIP_NO_GALOIS_FUSION");
+  if (const char *e = std::getenv("ABC_HIP_CHUNK")) s.chunk = (size_t)std::atol(e);
+  if (const char *e = std::getenv("ABC_HIP_FEW_LIMBS")) s.few_limbs = (size_t)std::atol(e);
+  if (const char *e = std::getenv("ABC_HIP_LANE_OFFSET_US")) s.lane_offset_us = (unsigned)std::atoi(e);
+  if (const char *e = std::getenv("ABC_HIP_LANES")) {
+    s.lanes = std::atoi(e);
+    if (s.lanes < 1) s.lanes = 1;
+    if (s.lanes > abc_hip_ctx::kMaxLanes) s.lanes = abc_hip_ctx::kMaxLanes;
+  }
+  c->sw = s;
+}
+
 static bool capturing(abc_hip_ctx *c) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(c->stream, &st) != hipSuccess) return false;
   return st != hipStreamCaptureStatusNone;
+}
+
+// Give every cached (free-listed) block back to the driver.  The stream is drained first: a cached block may still be
+// read by work that was enqueued before it was freed.
+static int trim_cache(abc_hip_ctx *c) {
+  std::lock_guard<std::mutex> lock(c->alloc_mu);
+  if (c->free_blocks.empty()) return 0;
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (auto &kv : c->free_blocks)
+    for (void *p : kv.second) {
+      c->block_size.erase(p);
+      (void)hipFree(p);
+    }
+  c->free_blocks.clear();
+  c->cached_bytes = 0;
+  return 0;
+}
+// hipMalloc; on failure flush this context's cache once and try again (the cache never shrinks by itself)
+static hipError_t malloc_retry(abc_hip_ctx *c, void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) return e;
+  (void)hipGetLastError();
+  if (trim_cache(c)) return e;
+  return hipMalloc(p, bytes);
 }
 
 int ensure_workspace(abc_hip_ctx *c, size_t bytes) {
@@ -35,7 +83,7 @@ int ensure_workspace(abc_hip_ctx *c, size_t bytes) {
     c->ws_bytes = 0;
   }
   size_t want = bytes + bytes / 8;
-  ABC_HIP_CHECK(hipMalloc(&c->ws, want));
+  ABC_HIP_CHECK(malloc_retry(c, &c->ws, want));
   c->ws_bytes = want;
   return 0;
 }
@@ -49,7 +97,7 @@ int ensure_aux(abc_hip_ctx *c, int which, size_t bytes) {
     c->aux[which] = nullptr;
     c->aux_bytes[which] = 0;
   }
-  ABC_HIP_CHECK(hipMalloc(&c->aux[which], bytes));
+  ABC_HIP_CHECK(malloc_retry(c, &c->aux[which], bytes));
   c->aux_bytes[which] = bytes;
   return 0;
 }
@@ -268,7 +316,8 @@ static int build_context(abc_hip_ctx *c) {
   ABC_HIP_CHECK(hipMemcpy(c->d_tw, h_tw.data(), h_tw.size() * 8, hipMemcpyHostToDevice));
   ABC_HIP_CHECK(hipMalloc(&c->d_ftw, h_ftw.size() * 8));
   ABC_HIP_CHECK(hipMemcpy(c->d_ftw, h_ftw.data(), h_ftw.size() * 8, hipMemcpyHostToDevice));
-  c->use_fp = (std::getenv("ABC_HIP_NO_FP64") == nullptr);
+  c->use_fp = !env_on("ABC_HIP_NO_FP64");
+  read_switches(c);
   ABC_HIP_CHECK(hipMalloc(&c->d_cst, sizeof(DevConst)));
   ABC_HIP_CHECK(hipMemcpy(c->d_cst, &k, sizeof(DevConst), hipMemcpyHostToDevice));
   if (bfv) {
@@ -522,7 +571,7 @@ int abc_hip_ctx_create(int scheme, int logn, const uint64_t *primes, int nprimes
       rc = 1;
     }
   }
-  if (!rc && !std::getenv("ABC_HIP_SYNC_ALLOC")) {
+  if (!rc && !env_on("ABC_HIP_SYNC_ALLOC")) {
     c->cache_alloc = true;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c->cache_cap = total_b / 4;  // at most a quarter of the device
@@ -541,8 +590,9 @@ void abc_hip_ctx_destroy(abc_hip_ctx *c) {
   for (auto &kv : c->d_galois) (void)hipFree(kv.second);
   (void)hipFree(c->ws);
   for (void *p : c->aux) (void)hipFree(p);
-  for (auto &kv : c->free_blocks)
-    for (void *p : kv.second) (void)hipFree(p);
+  // every block abc_hip_malloc ever handed out and that was not returned to the driver: cached ones and ones the caller
+  // still holds (a caller that frees after destroying the context would otherwise leak them)
+  for (auto &kv : c->block_size) (void)hipFree(kv.first);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -582,14 +632,18 @@ int abc_hip_sync(abc_hip_ctx *c) {
 // Caching allocator: a freed buffer goes to a per-context free list (exact-size buckets) instead of back to the
 // driver, and the next request of that size takes it -- no hipMalloc, no hipFree, no device synchronisation.  That is
 // safe because every use of a context's buffers is ordered on the context's stream (the internal lanes fork from and
-// join it inside each call): whatever still runs on a recycled buffer was issued before its new owner's first use.
-// It matters to the plugin classes, where the interpreter clones / drops a ciphertext on every variable read.
+// join it inside each call, also on error paths: LaneScope in abc_kernels_fused.hip): whatever still runs on a recycled
+// buffer was issued before its new owner's first use.  A buffer handed to ANOTHER context or stream is the caller's to
+// order (header).  It matters to the plugin classes, where the interpreter clones / drops a ciphertext on every
+// variable read.  The maps are guarded by a mutex (two host threads may share a context for allocation); the cache is
+// flushed by abc_hip_trim, when the cap is reached, and whenever a hipMalloc of this context fails.
 // (hipMallocAsync / hipFreeAsync were tried first and returned wrong results on some boxes of this pool when two
-// contexts alternated; ABC_HIP_SYNC_ALLOC=1 turns the cache off.)
+// contexts alternated -- analysis in DESIGN.md section 4b; ABC_HIP_SYNC_ALLOC=1 turns the cache off.)
 int abc_hip_malloc(abc_hip_ctx *c, void **d_ptr, size_t bytes) {
   CTX_GUARD(c);
   if (!bytes) bytes = 8;
   if (c->cache_alloc) {
+    std::lock_guard<std::mutex> lock(c->alloc_mu);
     auto it = c->free_blocks.find(bytes);
     if (it != c->free_blocks.end() && !it->second.empty()) {
       *d_ptr = it->second.back();
@@ -598,24 +652,51 @@ int abc_hip_malloc(abc_hip_ctx *c, void **d_ptr, size_t bytes) {
       return 0;
     }
   }
-  ABC_HIP_CHECK(hipMalloc(d_ptr, bytes));
-  if (c->cache_alloc) c->block_size[*d_ptr] = bytes;
+  ABC_HIP_CHECK(malloc_retry(c, d_ptr, bytes));
+  if (c->cache_alloc) {
+    std::lock_guard<std::mutex> lock(c->alloc_mu);
+    c->block_size[*d_ptr] = bytes;
+  }
   return 0;
 }
 int abc_hip_free(abc_hip_ctx *c, void *d_ptr) {
   CTX_GUARD(c);
   if (!d_ptr) return 0;
   if (c->cache_alloc) {
-    auto it = c->block_size.find(d_ptr);
-    if (it != c->block_size.end() && c->cached_bytes + it->second <= c->cache_cap) {
-      c->free_blocks[it->second].push_back(d_ptr);
-      c->cached_bytes += it->second;
-      return 0;
+    bool over_cap = false;
+    {
+      std::lock_guard<std::mutex> lock(c->alloc_mu);
+      auto it = c->block_size.find(d_ptr);
+      if (it != c->block_size.end()) {
+        if (c->cached_bytes + it->second <= c->cache_cap) {
+          c->free_blocks[it->second].push_back(d_ptr);
+          c->cached_bytes += it->second;
+          return 0;
+        }
+        c->block_size.erase(it);
+        over_cap = true;
+      }
     }
-    if (it != c->block_size.end()) c->block_size.erase(it);
+    // cap reached: exact-size buckets strand blocks when sizes vary, so give the whole cache back, not just this block
+    if (over_cap && trim_cache(c)) return 1;
   }
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   ABC_HIP_CHECK(hipFree(d_ptr));
+  return 0;
+}
+int abc_hip_trim(abc_hip_ctx *c) {
+  CTX_GUARD(c);
+  return trim_cache(c);
+}
+size_t abc_hip_cached_bytes(abc_hip_ctx *c) {
+  if (!c) return 0;
+  std::lock_guard<std::mutex> lock(c->alloc_mu);
+  return c->cached_bytes;
+}
+int abc_hip_ctx_reload_env(abc_hip_ctx *c) {
+  CTX_GUARD(c);
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  read_switches(c);
   return 0;
 }
 int abc_hip_memcpy_h2d(abc_hip_ctx *c, void *d, const void *h, size_t bytes) {
@@ -833,7 +914,6 @@ int abc_hip_keyswitch(abc_hip_ctx *c, const uint64_t *target, uint32_t key_kind,
 // ---- graph capture ----
 int abc_hip_graph_begin(abc_hip_ctx *c) {
   CTX_GUARD(c);
-  if (!c->stream) { set_error("graph capture needs an explicit stream: call abc_hip_set_stream with a non-default stream"); return 1; }
   ABC_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   return 0;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <mutex>
 #include <unordered_map>
 #include <string>
 #include <vector>
@@ -120,10 +121,20 @@ struct abc_hip_ctx {
   double *d_ftw = nullptr;
   // caching allocator behind abc_hip_malloc / abc_hip_free (abc_context.hip)
   bool cache_alloc = false;
+  std::mutex alloc_mu;  // guards the three members below
   size_t cached_bytes = 0, cache_cap = (size_t)8 << 30;
   std::unordered_map<size_t, std::vector<void *>> free_blocks;  // size -> cached blocks
   std::unordered_map<void *, size_t> block_size;                 // every live block handed out by abc_hip_malloc
   bool use_fp = true;  // fp64 transforms for primes < 2^50 (ABC_HIP_NO_FP64=1 forces the integer path)
+  // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
+  // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
+  struct Switches {
+    bool no_fused = false, no_split = false, no_split2 = false, no_tensor_decomp = false, no_tensor_intt = false;
+    bool tailmac_serial = false, no_galois_fusion = false;
+    size_t chunk = 0, few_limbs = 48;
+    int lanes = 2;
+    unsigned lane_offset_us = 0;
+  } sw;
   abc::DevConst *d_cst = nullptr;
   uint32_t *d_slot_map = nullptr;
   // keys (device)
@@ -155,6 +166,7 @@ void set_error(const std::string &msg);
 // workspace: grows on demand (never inside a timed region after warm-up)
 int ensure_workspace(abc_hip_ctx *c, size_t bytes);
 int ensure_aux(abc_hip_ctx *c, int which, size_t bytes);
+void read_switches(abc_hip_ctx *c);
 
 // ---- launchers implemented in the kernel translation units ----
 LimbMap key_limb_map(const abc_hip_ctx *c, int nl);  // 0..nl-1 -> data primes, nl -> special prime

@@ -252,7 +252,7 @@ static int launch_tensor_intt(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d
 }
 // -1: ring too large for an LDS-resident limb
 static int tensor_intt(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d, const LimbMap &map, int nlm, size_t count) {
-  if (std::getenv("ABC_HIP_NO_TENSOR_INTT")) return -1;
+  if (c->sw.no_tensor_intt) return -1;
   // single-ciphertext calls: the separate kernels spread a transform over many workgroups (launch_ntt, "few limbs")
   if (c->logn == 14 && count * 3 * (size_t)nlm <= 48) return -1;
   switch (c->logn) {
@@ -407,7 +407,7 @@ int bfv_multiply_plain(abc_hip_ctx *c, const u64 *ct, const u64 *plain, size_t p
   hipLaunchKernelGGL(k_plain_lift, dim3(grid_for(nplain * N, 256)), dim3(256), 0, c->stream, c->dc, plain, lifted, nplain);
   ABC_HIP_CHECK(hipGetLastError());
   if (launch_ntt_fwd(c, lifted, qmap, L, nplain * L)) return 1;
-  bool fp = c->use_fp && c->logn <= 14 && !std::getenv("ABC_HIP_NO_FUSED");
+  bool fp = c->use_fp && c->logn <= 14 && !c->sw.no_fused;
   for (int j = 0; j < L; j++) fp = fp && fp_ok(c->h_mods[j].bits);
   if (fp && (c->logn < 14 || count * size * L > 48)) {  // single-ciphertext calls keep the spread-out transforms
     const size_t ls = plain_stride ? (size_t)L * N : 0;

@@ -366,7 +366,7 @@ int launch_rescale(abc_hip_ctx *c, const u64 *in, u64 *out, int size, int nl, si
   if (nl < 2) { set_error("rescale: no limb left to drop"); return 1; }
   const size_t N = (size_t)c->n, polys = count * size;
   if (!polys) return 0;
-  bool fp = c->use_fp && c->logn <= 14 && in != out && !std::getenv("ABC_HIP_NO_FUSED");
+  bool fp = c->use_fp && c->logn <= 14 && in != out && !c->sw.no_fused;
   for (int j = 0; j < nl; j++) fp = fp && fp_ok(c->h_mods[j].bits);
   if (fp) switch (c->logn) {
       case 10: return launch_rescale_fp<10>(c, in, out, nl, polys);

@@ -29,8 +29,6 @@
 //                         it, subtract, scale by q_sp^-1, add c0 / c1.  BFV: inverse-transform the accumulated limb,
 //                         then the same subtract / scale / add in coefficient form
 // Algorithmic HBM bytes per multiply: 8N(6L + 2L(L+1)); measured: DESIGN.md section 4.
-#include <cstdlib>
-
 #include "abc_context.hpp"
 
 namespace abc {
@@ -795,7 +793,7 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
     if (!dec_ready)
       hipLaunchKernelGGL(k_fused_ks_decomp_ntt_fp<LB>, dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
     // cooperative form: nl wavefronts and 8.5 max(nl, 2) KiB of LDS per workgroup
-    if (dec_ready == 2 && nl <= 12 && !std::getenv("ABC_HIP_TAILMAC_SERIAL"))
+    if (dec_ready == 2 && nl <= 12 && !c->sw.tailmac_serial)
       hipLaunchKernelGGL((gelt ? k_fused_tailmac_coop_fp<true> : k_fused_tailmac_coop_fp<false>), dim3((unsigned)(cc * (nl + 1) * 16)),
                          dim3(64 * nl),
                          (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8, st, c->dc, (const double *)s.dec,
@@ -852,13 +850,7 @@ struct ChunkPlan {
 // Chunks alternate between two internal streams so that the HBM-streaming kernels of one chunk overlap the ALU-bound
 // transforms of the other; measured on MI355X: 256-pair chunks on two lanes beat one 512-pair chunk per lane.
 static ChunkPlan plan_chunks(const abc_hip_ctx *c, int nl, size_t count) {
-  ChunkPlan p{0, 2};
-  if (const char *e = std::getenv("ABC_HIP_CHUNK")) p.chunk = (size_t)std::atol(e);
-  if (const char *e = std::getenv("ABC_HIP_LANES")) {
-    p.lanes = std::atoi(e);
-    if (p.lanes < 1) p.lanes = 1;
-    if (p.lanes > abc_hip_ctx::kMaxLanes) p.lanes = abc_hip_ctx::kMaxLanes;
-  }
+  ChunkPlan p{c->sw.chunk, c->sw.lanes};
   if (count <= 8) p.lanes = 1;
   if (!p.chunk) {
     const size_t per_ct_bytes = fused_scratch_limbs(nl) * c->n * 8;
@@ -883,10 +875,8 @@ static int fork_lanes(abc_hip_ctx *c, int lanes) {
   ABC_HIP_CHECK(hipEventRecord(c->lane_fork, c->stream));
   for (int l = 0; l < lanes; l++) ABC_HIP_CHECK(hipStreamWaitEvent(c->lane[l], c->lane_fork, 0));
   // ABC_HIP_LANE_OFFSET_US: lane l starts l x this late, so that the lanes sit in different kernels of the sequence
-  if (const char *e = std::getenv("ABC_HIP_LANE_OFFSET_US")) {
-    const unsigned us = (unsigned)std::atoi(e);
-    for (int l = 1; l < lanes && us; l++) hipLaunchKernelGGL(k_lane_delay, dim3(1), dim3(64), 0, c->lane[l], us * 100u * l);
-  }
+  if (const unsigned us = c->sw.lane_offset_us)
+    for (int l = 1; l < lanes; l++) hipLaunchKernelGGL(k_lane_delay, dim3(1), dim3(64), 0, c->lane[l], us * 100u * l);
   return 0;
 }
 static int join_lanes(abc_hip_ctx *c, int lanes) {
@@ -898,6 +888,27 @@ static int join_lanes(abc_hip_ctx *c, int lanes) {
   return 0;
 }
 
+// fork on construction (fork()), join on every way out: an early `return 1` between the two would otherwise leave work on
+// the lanes that the context's stream -- and with it every later use or release of the buffers involved -- never waits for
+struct LaneScope {
+  abc_hip_ctx *c;
+  int lanes;
+  bool forked = false;
+  LaneScope(abc_hip_ctx *c_, int lanes_) : c(c_), lanes(lanes_) {}
+  int fork() {
+    if (fork_lanes(c, lanes)) return 1;
+    forked = true;
+    return 0;
+  }
+  int join() {
+    forked = false;
+    return join_lanes(c, lanes);
+  }
+  ~LaneScope() {
+    if (forked) (void)join_lanes(c, lanes);
+  }
+};
+
 // ---- CKKS multiply + relinearise ----
 template <int LB>
 static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count) {
@@ -905,7 +916,8 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
   const ChunkPlan p = plan_chunks(c, nl, count);
   const size_t per_ct = fused_scratch_limbs(nl) * N;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
-  if (fork_lanes(c, p.lanes)) return 1;
+  LaneScope scope(c, p.lanes);
+  if (scope.fork()) return 1;
   const size_t ctw = 2 * (size_t)nl * N;
   int turn = 0;
   for (size_t off = 0; off < count; off += p.chunk, turn++) {
@@ -913,9 +925,9 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
     const int l = (p.lanes > 1) ? turn % p.lanes : 0;
     hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
     const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, N);
-    const bool fuse_decomp = all_fp(c) && !std::getenv("ABC_HIP_NO_TENSOR_DECOMP");
+    const bool fuse_decomp = all_fp(c) && !c->sw.no_tensor_decomp;
     bool split = false;
-    if constexpr (LB == 14) split = fuse_decomp && !std::getenv("ABC_HIP_NO_SPLIT");
+    if constexpr (LB == 14) split = fuse_decomp && !c->sw.no_split;
     if constexpr (LB == 14) {
       if (split)
         hipLaunchKernelGGL(k_fused_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
@@ -935,14 +947,13 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
                             nl, cc, split ? 2 : (fuse_decomp ? 1 : 0)))
       return 1;
   }
-  return join_lanes(c, p.lanes);
+  return scope.join();
 }
 
 // -1: not applicable (ring too large for an LDS-resident limb) -> caller takes the generic path
 int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count) {
   if (c->logn > 14) return -1;
-  if (const char *e = std::getenv("ABC_HIP_NO_FUSED"))
-    if (e[0] == '1') return -1;
+  if (c->sw.no_fused) return -1;
   if (!count) return 0;
   switch (c->logn) {
     case 10: return run_mul_relin<10>(c, a, b, out, nl, count);
@@ -964,7 +975,8 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
   const ChunkPlan p = plan_chunks(c, nl, count);
   const size_t per_ct = fused_scratch_limbs(nl) * N;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
-  if (fork_lanes(c, p.lanes)) return 1;
+  LaneScope scope(c, p.lanes);
+  if (scope.fork()) return 1;
   int turn = 0;
   for (size_t off = 0; off < count; off += p.chunk, turn++) {
     const size_t cc = (count - off < p.chunk) ? count - off : p.chunk;
@@ -976,7 +988,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     size_t coef_stride = target_stride;
     bool split = false;
     if constexpr (LB == 14) {
-      split = all_fp(c) && !std::getenv("ABC_HIP_NO_SPLIT");
+      split = all_fp(c) && !c->sw.no_split;
       if (split && ckks)
         hipLaunchKernelGGL((gelt ? k_fused_operand_pass0_fp<LB, true, true> : k_fused_operand_pass0_fp<LB, true, false>),
                            dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, 0,
@@ -1003,14 +1015,14 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
                             addend_stride, add_c1, out + off * 2 * nl * N, nl, cc, split ? 2 : 0, gelt))
       return 1;
   }
-  return join_lanes(c, p.lanes);
+  return scope.join();
 }
 
 // CKKS rotation with the Galois permutation folded into the key switch (N = 2^14, fp64 split path): in [count][2][nl][N]
 // NTT form; out = (g(c0) + ks0, ks1), ks = KeySwitch(g(c1)).  -1: not applicable, caller permutes first.
 int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *out, int nl, size_t count) {
   if (c->logn != 14 || c->scheme != 2 || !all_fp(c) || in == out) return -1;
-  if (std::getenv("ABC_HIP_NO_SPLIT") || std::getenv("ABC_HIP_NO_FUSED") || std::getenv("ABC_HIP_NO_GALOIS_FUSION")) return -1;
+  if (c->sw.no_split || c->sw.no_fused || c->sw.no_galois_fusion) return -1;
   if (!count) return 0;
   const size_t N = (size_t)c->n, pw = (size_t)nl * N;
   return run_keyswitch<14>(c, in + pw, 2 * pw, key, out, nl, count, in, 2 * pw, false, elt);
@@ -1019,8 +1031,7 @@ int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *ou
 int keyswitch_fused(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count,
                     const u64 *addend, size_t addend_stride, bool add_c1) {
   if (c->logn > 14) return -1;
-  if (const char *e = std::getenv("ABC_HIP_NO_FUSED"))
-    if (e[0] == '1') return -1;
+  if (c->sw.no_fused) return -1;
   if (!count) return 0;
   switch (c->logn) {
     case 10: return run_keyswitch<10>(c, target, target_stride, key, out, nl, count, addend, addend_stride, add_c1);

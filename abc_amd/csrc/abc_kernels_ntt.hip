@@ -283,7 +283,7 @@ static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t
       // few limbs in flight (single-ciphertext calls): one workgroup per limb leaves most CUs idle for 17-30 us per
       // transform; spread each transform over 64 + 16 workgroups instead (strided radix-16 pass through HBM +
       // 1024-point blocks, the N > 2^14 machinery), trading an HBM round trip nobody misses at this size
-      static const size_t few = std::getenv("ABC_HIP_FEW_LIMBS") ? (size_t)std::atol(std::getenv("ABC_HIP_FEW_LIMBS")) : 48;
+      const size_t few = c->sw.few_limbs;
       if (total_limbs > few) return launch_block<14>(c, d, map, nl, total_limbs, 0, fwd, src, src2);
       if (src) {
         if (copy_sources(c, d, src, src2, total_limbs)) return 1;

@@ -2,19 +2,28 @@
 """bench.py -- homomorphic mul+relin/sec, CKKS N=2^14 (BASELINE.json metric) on N MI355X.
 
 One "step" = one pass of the hot path (SealCiphertext::multiply = Evaluator::multiply +
-relinearize_inplace, src/runtime/SealCiphertext.cpp:102-107) over a batch of B independent synthetic
-ciphertext pairs resident in HBM, through the C ABI (abc_hip_mul_relin).  Multi-GPU: the independent
-pairs are sharded over ranks (weak scaling, B per GPU fixed), no data-path collective; the result
-ciphertexts of the last step are gathered to rank 0 over RCCL after the timed region (the one exchange
-the path has).
+relinearize_inplace, src/runtime/SealCiphertext.cpp:102-107) over this rank's share of a batch of
+independent synthetic ciphertext pairs resident in HBM, through the C ABI (abc_hip_mul_relin).
+
+Multi-GPU: the independent pairs are sharded over ranks, one process per GPU, no
+data-path collective; the result ciphertexts of the last step are gathered to rank 0 over RCCL after the
+timed region and timed separately (`gather_ms`).  Default = STRONG scaling: `--total-batch` pairs (8192)
+are split over the ranks, so per-GPU work shrinks as N grows; `--batch B` instead fixes B pairs per rank
+(weak scaling).
+
+Launch: `python bench.py --gpus N` starts the N ranks itself (fresh child processes, spawned before this
+process touches torch or HIP); under `torch.distributed.run` (RANK set) it runs as the rank it is told.
 
 Prints ONE JSON line (rank 0) with `roofline` (HIP-event-timed hot launch vs the 8 TB/s HBM peak,
-algorithmic bytes 8N(6L+2L(L+1)) per multiply) and `cpu_baseline` (the CPU oracle port on host cores).
+algorithmic bytes 8N(6L+2L(L+1)) per multiply) and, at N=1, `cpu_baseline` (the CPU oracle port on host
+cores: one thread and all cores).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,36 +32,81 @@ sys.path.insert(0, ROOT)
 
 N = 16384
 BITS = [50, 40, 40, 40, 50]  # 4 data limbs + special prime (config 3 chain)
+BITS_60 = [60, 40, 40, 40, 60]  # a SEAL-typical chain: 60-bit primes take the integer kernels, not the fp64 ones
 L = 4
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 ALGO_BYTES = 8 * N * (6 * L + 2 * L * (L + 1))  # = 8 388 608 B per mul+relin
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="independent ciphertext pairs per GPU per step")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound of the cpu_baseline leg")
+    ap.add_argument("--total-batch", type=int, default=8192,
+                    help="strong scaling (default): independent ciphertext pairs per step over ALL ranks")
+    ap.add_argument("--batch", type=int, default=0, help="weak scaling: pairs per GPU per step (overrides --total-batch)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of each cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-60bit", action="store_true", help="skip the 60-bit-prime (integer kernel) side measurement")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="rehearse launch + sharding + gather with gloo on the CPU (no device work, no timing claims)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(primes, seconds):
-    """The oracle (a port of SEAL's algorithms, kind="port") timed on this host: one mul+relin per thread at a
-    time over the independent batch, on all host cores."""
-    import multiprocessing as mp
-    cores = os.cpu_count() or 1
-    workers = min(cores, 64)
-    with mp.get_context("spawn").Pool(workers) as pool:
-        res = pool.starmap(_cpu_worker, [(primes, seconds, w) for w in range(workers)])
-    ops = sum(r[0] for r in res)
-    wall = max(r[1] for r in res)
-    return {"value": ops / wall, "unit": "mul+relin/s", "cores": workers, "kind": "port",
-            "sample": "%d mul+relin of the same CKKS N=16384 L=4 workload over %d threads in %.1f s" % (ops, workers, wall)}
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: N fresh rank processes, started before anything in this process initialises the GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
+def launch_ranks(args):
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    # relay rank 0's output; if any rank dies, stop the others (they would wait in the rendezvous for ever)
+    out0 = []
+    rc = 0
+    import threading
+
+    def pump():
+        for raw in procs[0].stdout:
+            out0.append(raw.decode())
+
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    live = set(range(args.gpus))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for o in live:
+                    procs[o].terminate()  # exactly the PIDs started above
+        time.sleep(0.05)
+    th.join(timeout=5)
+    sys.stdout.write("".join(out0))
+    sys.stdout.flush()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle: a port of SEAL 3.6's algorithms; no SEAL binary or source exists in this image)
+# ---------------------------------------------------------------------------------------------------------------------
 def _cpu_worker(primes, seconds, w):
     import numpy as np
     from oracle import oracle_py as om
@@ -62,19 +116,40 @@ def _cpu_worker(primes, seconds, w):
     a = np.stack([rng.integers(0, q, size=(2, N), dtype=np.uint64) for q in primes[:L]], axis=1)
     b = np.stack([rng.integers(0, q, size=(2, N), dtype=np.uint64) for q in primes[:L]], axis=1)
     o.time_mul_relin(a, b, 1)
+    per_op = []  # seconds per mul+relin, one sample per group of 4 (scratch preallocated outside the clock)
     t0 = time.time()
-    ops = 0
     while time.time() - t0 < seconds:
-        o.time_mul_relin(a, b, 4)
-        ops += 4
-    return ops, time.time() - t0
+        per_op.append(o.time_mul_relin(a, b, 4) / 4)
+    return per_op, time.time() - t0
+
+
+def cpu_baseline(primes, seconds):
+    """One mul+relin per thread at a time over the independent batch: first ONE thread alone (the figure that
+    compares with a single-threaded seal::Evaluator), then all host cores.  `value` = the all-core aggregate."""
+    import multiprocessing as mp
+    import statistics
+    single, _ = _cpu_worker(primes, min(seconds, 5.0), 0)
+    cores = os.cpu_count() or 1
+    workers = min(cores, 64)
+    with mp.get_context("spawn").Pool(workers) as pool:
+        res = pool.starmap(_cpu_worker, [(primes, seconds, w) for w in range(workers)])
+    ops = 4 * sum(len(r[0]) for r in res)
+    wall = max(r[1] for r in res)
+    med_all = statistics.median([t for r in res for t in r[0]])
+    return {"value": ops / wall, "unit": "mul+relin/s", "cores": workers, "kind": "port",
+            "one_thread": {"value": 1.0 / statistics.median(single), "median_ms_per_op": statistics.median(single) * 1e3,
+                           "runs": 4 * len(single)},
+            "median_ms_per_op_all_cores_busy": med_all * 1e3,
+            "seal_binary": "absent: no SEAL build or source in this image, the port restates SEAL 3.6's algorithms",
+            "sample": "%d mul+relin of the same CKKS N=16384 L=4 workload over %d threads in %.1f s "
+                      "(plus %d on one thread alone)" % (ops, workers, wall, 4 * len(single))}
 
 
 def measured_traffic(batch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
     separate runs and corrected as MI355X_MICROARCH.md prescribes; newest profiles/r*_pmc_traffic.json,
-    produced by tools/pmc_traffic.sh), scaled to this
-    batch.  bench.py cannot collect PMC counters itself; None if the profile is absent."""
+    produced by tools/pmc_traffic.sh), scaled to this batch.  bench.py cannot collect PMC counters itself; None
+    if the profile is absent."""
     try:
         import glob
         latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
@@ -84,11 +159,43 @@ def measured_traffic(batch):
         return None
 
 
-def main():
-    args = parse()
+def my_share(args, rank, world):
+    """(first pair, number of pairs) of this rank, and the scaling mode"""
+    from abc_amd.sharding import shard_range
+    if args.batch > 0:
+        return rank * args.batch, args.batch, args.batch * world, "weak"
+    lo, hi = shard_range(args.total_batch, rank, world)
+    return lo, hi - lo, args.total_batch, "strong"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU rehearsal of the multi-rank plumbing (tests/test_bench_launcher.py): gloo, no device, no numbers claimed
+# ---------------------------------------------------------------------------------------------------------------------
+def dry_run_cpu(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    from abc_amd.sharding import gather_results
+    if world > 1:
+        dist.init_process_group("gloo")
+    lo, B, total, mode = my_share(args, rank, world)
+    local = torch.arange(lo, lo + B, dtype=torch.int64).reshape(B, 1).repeat(1, 4)  # stand-in "result ciphertexts"
+    t0 = time.perf_counter()
+    gathered = gather_results(local, total, dst=0) if world > 1 else local
+    gather_ms = (time.perf_counter() - t0) * 1e3
+    if rank == 0:
+        assert gathered.shape[0] == total and bool((gathered[:, 0] == torch.arange(total)).all())
+        print(json.dumps({"dry_run": True, "n_gpus": dist.get_world_size() if world > 1 else 1, "scaling": mode,
+                          "total_batch": total, "batch_rank0": B, "gather_ms": gather_ms}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -101,24 +208,27 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    n_gpus = dist.get_world_size() if world > 1 else 1  # the ranks RCCL actually sees
 
+    first, B, total, mode = my_share(args, rank, world)
+    stream = torch.cuda.Stream(device=dev)  # inputs are generated on, and the C ABI launches into, this one stream
     primes = capi.create_primes(N, BITS)
     g = capi.Context(capi.CKKS, N, primes, device=local_rank)
-    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.set_stream(stream.cuda_stream)
     g.keygen(0xABC00001)  # keys replicated on every device
 
-    B = args.batch
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
 
-    def rand_ct():
-        t = torch.empty((B, 2, L, N), dtype=torch.int64, device=dev)
-        for j, q in enumerate(primes[:L]):
-            t[:, :, j, :] = torch.randint(0, q, (B, 2, N), dtype=torch.int64, device=dev, generator=gen)
+    def rand_ct(chain, count):
+        t = torch.empty((count, 2, L, N), dtype=torch.int64, device=dev)
+        for j, q in enumerate(chain[:L]):
+            t[:, :, j, :] = torch.randint(0, q, (count, 2, N), dtype=torch.int64, device=dev, generator=gen)
         return t
 
-    a, b = rand_ct(), rand_ct()  # uniformly random residues = what ciphertexts look like
-    out = torch.empty_like(a)
+    with torch.cuda.stream(stream):
+        a, b = rand_ct(primes, B), rand_ct(primes, B)  # uniformly random residues = what ciphertexts look like
+        out = torch.empty_like(a)
     pa, pb, po = (C.c_void_p(t.data_ptr()) for t in (a, b, out))
 
     def step():
@@ -140,48 +250,93 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gather_ms = None
     if world > 1:
         tt = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, ev_ms = float(tt[0]), float(tt[1])
-        # the path's only exchange: gather the result ciphertexts of the last step on rank 0
+        elapsed, ev_ms_max = float(tt[0]), float(tt[1])
+        # the path's only exchange: gather the result ciphertexts of the last step on rank 0 (outside the timed region)
         from abc_amd.sharding import gather_results
-        gathered = gather_results(out, B * world, dst=0)
         torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        gathered = gather_results(out, total, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
-            assert gathered.shape[0] == B * world
+            assert gathered.shape[0] == total
+        del gathered
 
     if rank == 0:
-        total_ops = B * world * args.steps
-        value = total_ops / elapsed
-        launch_ms = ev_ms / args.steps  # one hot launch = one abc_hip_mul_relin over B pairs
+        value = total * args.steps / elapsed
+        launch_ms = ev_ms / args.steps  # one hot launch = one abc_hip_mul_relin over this rank's B pairs
         achieved = (ALGO_BYTES * B) / (launch_ms * 1e-3) / 1e9
         line = {
             "metric": "homomorphic mul+relin/sec, CKKS N=2^14", "value": value, "unit": "mul+relin/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 (transforms: exact integer arithmetic in f64)", "data": "synthetic",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": mode, "vs_baseline": None,
+            "dtype": "u64 (transforms: exact integer arithmetic in f64)", "data": "synthetic",
             "config": {"workload": "CKKS N=16384, 4 data limbs {50,40,40,40} + special 50-bit prime, ct x ct multiply + relinearize",
-                       "batch_per_gpu": B, "sharding": "independent ciphertext pairs per rank, result gather only"},
+                       "total_batch": total, "batch_rank0": B,
+                       "sharding": "independent ciphertext pairs per rank, result gather only"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
-                         "kernel": "abc_hip_mul_relin = k_fused_tensor_pass0_fp + k_fused_tailmac_coop_fp (dominant) + "
-                                   "k_fused_ks_special_intt_fp + k_fused_ks_moddown_fp",
+                         "kernel": "abc_hip_mul_relin (rank 0's launch): see DESIGN.md section 4 for its kernels",
                          "algorithmic_bytes_per_launch": ALGO_BYTES * B, "launch_ms": launch_ms},
         }
-        if not args.no_cpu and world == 1:  # CPU leg on rank 0 at N=1 only
-            # parity spot check of the measured path against the oracle, then the CPU leg
-            from oracle import oracle_py as om
-            o = om.Oracle(om.CKKS, N, primes)
-            o.keygen(0xABC00001)
-            ha = a[0].cpu().numpy().view(np.uint64)
-            hb = b[0].cpu().numpy().view(np.uint64)
-            ho = out[0].cpu().numpy().view(np.uint64)
+        if gather_ms is not None:
+            line["gather_ms"] = gather_ms
+        # parity spot check of the measured path against the oracle: first / chunk-boundary / last pairs
+        from oracle import oracle_py as om
+        o = om.Oracle(om.CKKS, N, primes)
+        o.keygen(0xABC00001)
+        checked = sorted({i for i in (0, 255, 256, B - 1) if 0 <= i < B})
+        for i in checked:
+            ha, hb, ho = (t[i].cpu().numpy().view(np.uint64) for t in (a, b, out))
             if not np.array_equal(o.mul_relin(ha, hb), ho):
-                raise SystemExit("bench: GPU result differs from the oracle -- number is invalid")
+                raise SystemExit("bench: GPU result of pair %d differs from the oracle -- number is invalid" % i)
+        line["checked_pairs_vs_oracle"] = checked
+        if world == 1 and not args.no_60bit:
+            # the headline chain keeps every key prime below 2^50 (fp64 butterflies); SEAL-typical 60-bit primes run the
+            # integer kernels instead -- reported beside it so the precondition of `value` is visible
+            del a, b, out
+            p60 = capi.create_primes(N, BITS_60)
+            g60 = capi.Context(capi.CKKS, N, p60, device=local_rank)
+            g60.set_stream(stream.cuda_stream)
+            g60.keygen(0xABC00001)
+            B60 = min(B, 1024)
+            with torch.cuda.stream(stream):
+                a6, b6 = rand_ct(p60, B60), rand_ct(p60, B60)
+                o6 = torch.empty_like(a6)
+            p6 = [C.c_void_p(t.data_ptr()) for t in (a6, b6, o6)]
+            for _ in range(2):
+                g60.op("mul_relin", *p6, L, C.c_size_t(B60))
+            torch.cuda.synchronize()
+            t6 = time.perf_counter()
+            for _ in range(5):
+                g60.op("mul_relin", *p6, L, C.c_size_t(B60))
+            torch.cuda.synchronize()
+            line["value_60bit_primes"] = 5 * B60 / (time.perf_counter() - t6)
+            o60 = om.Oracle(om.CKKS, N, p60)
+            o60.keygen(0xABC00001)
+            if not np.array_equal(o60.mul_relin(a6[B60 - 1].cpu().numpy().view(np.uint64), b6[B60 - 1].cpu().numpy().view(np.uint64)),
+                                  o6[B60 - 1].cpu().numpy().view(np.uint64)):
+                raise SystemExit("bench: 60-bit chain result differs from the oracle")
+            g60.close()
+        if not args.no_cpu and world == 1:  # CPU leg on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(primes, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # nothing above this line has imported torch or touched HIP: the ranks are fresh processes
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -50,8 +50,16 @@ uint64_t abc_hip_plain_modulus_batching(size_t n, int bits);
 /* seal::CoeffModulus::Create(N, bit_sizes) ordering, for CKKS chains */
 int abc_hip_create_primes(size_t n, const int *bit_sizes, int count, uint64_t *h_out);
 int abc_hip_ctx_info(const abc_hip_ctx *ctx, int what); /* 0 scheme, 1 logn, 2 nprimes, 3 L, 4 device */
+/* Every operation of the context is enqueued on `hip_stream` from now on.  NULL does NOT mean HIP's legacy default
+ * stream: it selects the context's own private non-blocking stream again (the state after abc_hip_ctx_create), which is
+ * not ordered against anything else -- a caller that produces inputs on another stream (e.g. torch's current stream, whose
+ * handle is 0 for the default stream) must synchronise that stream before the call and abc_hip_sync after it, or pass a
+ * real stream handle here (bench.py creates a torch.cuda.Stream and passes its handle). */
 int abc_hip_set_stream(abc_hip_ctx *ctx, void *hip_stream);
 int abc_hip_sync(abc_hip_ctx *ctx);
+/* The ABC_HIP_* path switches (README) are read when the context is created, not per operation; this re-reads them
+ * (drains the stream first).  For A/B timing and the parity tests of the fallback paths. */
+int abc_hip_ctx_reload_env(abc_hip_ctx *ctx);
 
 /* ---- device memory (so that FFI callers need no HIP runtime binding) ----
  * Freed buffers are cached per context and recycled by size, so a buffer may be freed right after the last operation
@@ -59,6 +67,10 @@ int abc_hip_sync(abc_hip_ctx *ctx);
  * ABC_HIP_SYNC_ALLOC=1 selects plain hipMalloc / synchronise + hipFree. */
 int abc_hip_malloc(abc_hip_ctx *ctx, void **d_ptr, size_t bytes);
 int abc_hip_free(abc_hip_ctx *ctx, void *d_ptr);
+/* hand every cached (freed, not yet reused) buffer back to the driver; also done automatically when a device
+ * allocation of this context fails and when the cache reaches its cap (a quarter of the device) */
+int abc_hip_trim(abc_hip_ctx *ctx);
+size_t abc_hip_cached_bytes(abc_hip_ctx *ctx);
 int abc_hip_memcpy_h2d(abc_hip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int abc_hip_memcpy_d2h(abc_hip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 /* seal::Ciphertext copy-ctor = SealCiphertext::clone, src/runtime/SealCiphertext.cpp:13-16,71-78 */

@@ -23,6 +23,29 @@
 #include <string.h>
 #include <time.h>
 
+
+/* Scratch allocation.  Outside the timed loop of orc_time_mul_relin these are malloc / free.  Inside it they bump a
+ * thread-local arena that was sized and touched before the clock started, so the CPU baseline does not time the C
+ * library's allocator or first-touch page faults (SEAL itself draws its temporaries from a memory pool). */
+static __thread unsigned char *g_arena = NULL;
+static __thread size_t g_arena_size = 0, g_arena_used = 0;
+static void *orc_salloc(size_t bytes) {
+  if (!g_arena) return malloc(bytes);
+  size_t need = (bytes + 63) & ~(size_t)63;
+  if (g_arena_used + need > g_arena_size) return NULL; /* sized generously below: cannot happen */
+  void *p = g_arena + g_arena_used;
+  g_arena_used += need;
+  return p;
+}
+static void *orc_szalloc(size_t bytes) {
+  void *p = orc_salloc(bytes);
+  if (p) memset(p, 0, bytes);
+  return p;
+}
+static void orc_sfree(void *p) {
+  if (!g_arena) free(p);
+}
+
 void orc_scaled_plain_addsub(const orc_ctx *c, const uint64_t *plain, uint64_t *poly, int sub);
 
 void orc_ntt_forward(const orc_ctx *c, int i, uint64_t *a) { orc_ntt_fwd(a, &c->ntt[i]); }
@@ -74,13 +97,13 @@ int orc_keyswitch(const orc_ctx *c, const uint64_t *target, int nl, const uint64
   int K = c->nkey;
   int ckks = (c->scheme == ORC_SCHEME_CKKS);
   int rns = nl + 1;
-  uint64_t *tcoef = (uint64_t *)malloc((size_t)nl * n * 8);
+  uint64_t *tcoef = (uint64_t *)orc_salloc((size_t)nl * n * 8);
   memcpy(tcoef, target, (size_t)nl * n * 8);
   if (ckks)
     for (int j = 0; j < nl; j++) orc_ntt_inv(tcoef + (size_t)j * n, &c->ntt[j]);
-  uint64_t *prod = (uint64_t *)calloc((size_t)2 * rns * n, 8); /* [2][rns][n] */
-  uint64_t *tntt = (uint64_t *)malloc(n * 8);
-  u128 *acc = (u128 *)malloc((size_t)2 * n * sizeof(u128));
+  uint64_t *prod = (uint64_t *)orc_szalloc((size_t)2 * rns * n * 8); /* [2][rns][n] */
+  uint64_t *tntt = (uint64_t *)orc_salloc(n * 8);
+  u128 *acc = (u128 *)orc_salloc((size_t)2 * n * sizeof(u128));
   for (int I = 0; I < rns; I++) {
     int ki = (I == nl) ? K - 1 : I;
     const orc_mod *mk = &c->qmod[ki];
@@ -128,7 +151,7 @@ int orc_keyswitch(const orc_ctx *c, const uint64_t *target, int nl, const uint64
         dst[k] = orc_mulmod_b(orc_sub_mod(pj[k], tntt[k], qj), c->inv_special_mod_q[j], mj);
     }
   }
-  free(acc); free(tntt); free(prod); free(tcoef);
+  orc_sfree(acc); orc_sfree(tntt); orc_sfree(prod); orc_sfree(tcoef);
   return 0;
 }
 
@@ -136,10 +159,10 @@ int orc_relinearize(const orc_ctx *c, const uint64_t *ct3, int nl, uint64_t *out
   /* [SEAL-recall: Evaluator::relinearize_internal, size 3 -> 2] */
   size_t n = c->n;
   if (!c->relin) return -1;
-  uint64_t *ks = (uint64_t *)malloc((size_t)2 * nl * n * 8);
+  uint64_t *ks = (uint64_t *)orc_salloc((size_t)2 * nl * n * 8);
   orc_keyswitch(c, ct3 + (size_t)2 * nl * n, nl, c->relin, ks);
   orc_add(c, ct3, ks, 2, nl, out2);
-  free(ks);
+  orc_sfree(ks);
   return 0;
 }
 
@@ -180,14 +203,14 @@ int orc_apply_galois(const orc_ctx *c, const uint64_t *ct, int nl, uint32_t elt,
   for (int i = 0; i < c->ngal; i++) if (c->gal_elt[i] == elt) key = c->gal_key[i];
   if (!key) return -1;
   size_t pw = (size_t)nl * n;
-  uint64_t *g0 = (uint64_t *)malloc(pw * 8), *g1 = (uint64_t *)malloc(pw * 8);
-  uint64_t *ks = (uint64_t *)malloc(2 * pw * 8);
+  uint64_t *g0 = (uint64_t *)orc_salloc(pw * 8), *g1 = (uint64_t *)orc_salloc(pw * 8);
+  uint64_t *ks = (uint64_t *)orc_salloc(2 * pw * 8);
   orc_galois_permute(c, ct, nl, elt, ntt_form, g0);
   orc_galois_permute(c, ct + pw, nl, elt, ntt_form, g1);
   orc_keyswitch(c, g1, nl, key, ks);
   orc_add(c, g0, ks, 1, nl, out2);
   memcpy(out2 + pw, ks + pw, pw * 8);
-  free(ks); free(g1); free(g0);
+  orc_sfree(ks); orc_sfree(g1); orc_sfree(g0);
   return 0;
 }
 
@@ -202,7 +225,7 @@ int orc_rotate(const orc_ctx *c, const uint64_t *ct, int nl, int steps, uint64_t
   int naf[40];
   int cnt = orc_naf(steps, naf);
   if (cnt == 1) return -3; /* "Galois key not present" */
-  uint64_t *cur = (uint64_t *)malloc(words * 8), *nxt = (uint64_t *)malloc(words * 8);
+  uint64_t *cur = (uint64_t *)orc_salloc(words * 8), *nxt = (uint64_t *)orc_salloc(words * 8);
   memcpy(cur, ct, words * 8);
   int rc = 0;
   for (int i = 0; i < cnt && !rc; i++) {
@@ -211,7 +234,7 @@ int orc_rotate(const orc_ctx *c, const uint64_t *ct, int nl, int steps, uint64_t
     uint64_t *t = cur; cur = nxt; nxt = t;
   }
   memcpy(out2, cur, words * 8);
-  free(cur); free(nxt);
+  orc_sfree(cur); orc_sfree(nxt);
   return rc;
 }
 
@@ -225,11 +248,11 @@ static void behz_extend(const orc_ctx *c, const uint64_t *poly /*[L][n] coeff*/,
   memcpy(q_ntt, poly, (size_t)L * n * 8);
   for (int j = 0; j < L; j++) orc_ntt_fwd(q_ntt + (size_t)j * n, &c->ntt[j]);
   /* fastbconv_m_tilde */
-  uint64_t *tmp = (uint64_t *)malloc((size_t)L * n * 8);
+  uint64_t *tmp = (uint64_t *)orc_salloc((size_t)L * n * 8);
   for (int j = 0; j < L; j++)
     for (size_t k = 0; k < n; k++)
       tmp[(size_t)j * n + k] = orc_mulmod_b(poly[(size_t)j * n + k], b->mtilde_mod_q[j], &c->qmod[j]);
-  uint64_t *ext = (uint64_t *)malloc((size_t)(nBsk + 1) * n * 8);
+  uint64_t *ext = (uint64_t *)orc_salloc((size_t)(nBsk + 1) * n * 8);
   orc_bconv_apply(&b->q_to_Bsk, tmp, ext, n);
   orc_bconv_apply(&b->q_to_mtilde, tmp, ext + (size_t)nBsk * n, n);
   /* sm_mrq */
@@ -245,7 +268,7 @@ static void behz_extend(const orc_ctx *c, const uint64_t *poly /*[L][n] coeff*/,
     }
     orc_ntt_fwd(bsk_ntt + (size_t)j * n, &b->Bsk_ntt[j]);
   }
-  free(ext); free(tmp);
+  orc_sfree(ext); orc_sfree(tmp);
 }
 
 int orc_bfv_multiply(const orc_ctx *c, const uint64_t *a, const uint64_t *bb, uint64_t *out3) {
@@ -255,13 +278,13 @@ int orc_bfv_multiply(const orc_ctx *c, const uint64_t *a, const uint64_t *bb, ui
   size_t n = c->n;
   int L = c->L, nBsk = b->nBsk;
   size_t qw = (size_t)L * n, bw = (size_t)nBsk * n;
-  uint64_t *aq = (uint64_t *)malloc(2 * qw * 8), *bq = (uint64_t *)malloc(2 * qw * 8);
-  uint64_t *aB = (uint64_t *)malloc(2 * bw * 8), *bB = (uint64_t *)malloc(2 * bw * 8);
+  uint64_t *aq = (uint64_t *)orc_salloc(2 * qw * 8), *bq = (uint64_t *)orc_salloc(2 * qw * 8);
+  uint64_t *aB = (uint64_t *)orc_salloc(2 * bw * 8), *bB = (uint64_t *)orc_salloc(2 * bw * 8);
   for (int p = 0; p < 2; p++) {
     behz_extend(c, a + p * qw, aq + p * qw, aB + p * bw);
     behz_extend(c, bb + p * qw, bq + p * qw, bB + p * bw);
   }
-  uint64_t *dq = (uint64_t *)malloc(3 * qw * 8), *dB = (uint64_t *)malloc(3 * bw * 8);
+  uint64_t *dq = (uint64_t *)orc_salloc(3 * qw * 8), *dB = (uint64_t *)orc_salloc(3 * bw * 8);
   /* step (4): dyadic tensor in both bases; step (5): inverse NTT */
   for (int j = 0; j < L; j++) {
     const orc_mod *m = &c->qmod[j];
@@ -287,8 +310,8 @@ int orc_bfv_multiply(const orc_ctx *c, const uint64_t *a, const uint64_t *bb, ui
   }
   /* steps (6)-(8) per output polynomial */
   uint64_t t = c->t.q;
-  uint64_t *conv = (uint64_t *)malloc(bw * 8), *fl = (uint64_t *)malloc(bw * 8);
-  uint64_t *msk = (uint64_t *)malloc(n * 8);
+  uint64_t *conv = (uint64_t *)orc_salloc(bw * 8), *fl = (uint64_t *)orc_salloc(bw * 8);
+  uint64_t *msk = (uint64_t *)orc_salloc(n * 8);
   for (int p = 0; p < 3; p++) {
     uint64_t *pq = dq + p * qw, *pB = dB + p * bw;
     for (int j = 0; j < L; j++)
@@ -320,16 +343,16 @@ int orc_bfv_multiply(const orc_ctx *c, const uint64_t *a, const uint64_t *bb, ui
       }
     }
   }
-  free(msk); free(fl); free(conv); free(dB); free(dq); free(bB); free(aB); free(bq); free(aq);
+  orc_sfree(msk); orc_sfree(fl); orc_sfree(conv); orc_sfree(dB); orc_sfree(dq); orc_sfree(bB); orc_sfree(aB); orc_sfree(bq); orc_sfree(aq);
   return 0;
 }
 
 int orc_bfv_mul_relin(const orc_ctx *c, const uint64_t *a, const uint64_t *b, uint64_t *out2) {
   /* SealCiphertext::multiply = multiply + relinearize_inplace (src/runtime/SealCiphertext.cpp:102-107) */
-  uint64_t *t3 = (uint64_t *)malloc((size_t)3 * c->L * c->n * 8);
+  uint64_t *t3 = (uint64_t *)orc_salloc((size_t)3 * c->L * c->n * 8);
   int rc = orc_bfv_multiply(c, a, b, t3);
   if (!rc) rc = orc_relinearize(c, t3, c->L, out2);
-  free(t3);
+  orc_sfree(t3);
   return rc;
 }
 
@@ -339,7 +362,7 @@ int orc_bfv_multiply_plain(const orc_ctx *c, const uint64_t *ct, int size, const
    * NTT, dyadic multiply, INTT.  Residues are canonical, so SEAL's mono-coefficient shortcut agrees. */
   size_t n = c->n;
   int L = c->L;
-  uint64_t *pl = (uint64_t *)malloc(n * 8), *tmp = (uint64_t *)malloc(n * 8);
+  uint64_t *pl = (uint64_t *)orc_salloc(n * 8), *tmp = (uint64_t *)orc_salloc(n * 8);
   for (int j = 0; j < L; j++) {
     const orc_mod *m = &c->qmod[j];
     for (size_t k = 0; k < n; k++)
@@ -354,7 +377,7 @@ int orc_bfv_multiply_plain(const orc_ctx *c, const uint64_t *ct, int size, const
       memcpy(out + o, tmp, n * 8);
     }
   }
-  free(tmp); free(pl);
+  orc_sfree(tmp); orc_sfree(pl);
   return 0;
 }
 int orc_bfv_add_plain(const orc_ctx *c, const uint64_t *ct, int size, const uint64_t *plain, uint64_t *out) {
@@ -385,10 +408,10 @@ int orc_ckks_multiply(const orc_ctx *c, const uint64_t *a, const uint64_t *b, in
   return 0;
 }
 int orc_ckks_mul_relin(const orc_ctx *c, const uint64_t *a, const uint64_t *b, int nl, uint64_t *out2) {
-  uint64_t *t3 = (uint64_t *)malloc((size_t)3 * nl * c->n * 8);
+  uint64_t *t3 = (uint64_t *)orc_salloc((size_t)3 * nl * c->n * 8);
   orc_ckks_multiply(c, a, b, nl, t3);
   int rc = orc_relinearize(c, t3, nl, out2);
-  free(t3);
+  orc_sfree(t3);
   return rc;
 }
 int orc_ckks_rescale(const orc_ctx *c, const uint64_t *ct, int size, int nl, uint64_t *out) {
@@ -398,7 +421,7 @@ int orc_ckks_rescale(const orc_ctx *c, const uint64_t *ct, int size, int nl, uin
   int last = nl - 1;
   const orc_mod *ml = &c->qmod[last];
   uint64_t half = ml->q >> 1;
-  uint64_t *li = (uint64_t *)malloc(n * 8), *tmp = (uint64_t *)malloc(n * 8);
+  uint64_t *li = (uint64_t *)orc_salloc(n * 8), *tmp = (uint64_t *)orc_salloc(n * 8);
   for (int p = 0; p < size; p++) {
     memcpy(li, ct + ((size_t)p * nl + last) * n, n * 8);
     orc_ntt_inv(li, &c->ntt[last]);
@@ -414,7 +437,7 @@ int orc_ckks_rescale(const orc_ctx *c, const uint64_t *ct, int size, int nl, uin
         dst[k] = orc_mulmod_b(orc_sub_mod(src[k], tmp[k], mj->q), c->inv_qlast_mod_q[last][j], mj);
     }
   }
-  free(tmp); free(li);
+  orc_sfree(tmp); orc_sfree(li);
   return 0;
 }
 int orc_ckks_mod_switch(const orc_ctx *c, const uint64_t *ct, int size, int nl, uint64_t *out) {
@@ -449,11 +472,21 @@ int orc_ckks_add_plain(const orc_ctx *c, const uint64_t *ct, int size, int nl, c
 /* ---------- CPU baseline timing ---------- */
 double orc_time_mul_relin(const orc_ctx *c, const uint64_t *a, const uint64_t *b, int nl, int iters, uint64_t *out2) {
   struct timespec t0, t1;
+  /* arena: every temporary of one mul+relin (< 256 limbs at any scheme / level), touched once before timing */
+  size_t bytes = (size_t)256 * c->n * 8;
+  unsigned char *arena = (unsigned char *)malloc(bytes);
+  if (arena) {
+    memset(arena, 0, bytes);
+    g_arena = arena; g_arena_size = bytes;
+  }
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int i = 0; i < iters; i++) {
+    g_arena_used = 0;
     if (c->scheme == ORC_SCHEME_CKKS) orc_ckks_mul_relin(c, a, b, nl, out2);
     else orc_bfv_mul_relin(c, a, b, out2);
   }
   clock_gettime(CLOCK_MONOTONIC, &t1);
+  g_arena = NULL; g_arena_size = g_arena_used = 0;
+  free(arena);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

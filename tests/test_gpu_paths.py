@@ -169,3 +169,102 @@ def test_fp64_and_integer_paths_agree_on_random_residues(oracle14, capi, monkeyp
             _same("round %d rescale nl=%d" % (rnd, nl), g_fp.rescale(a), g_int.rescale(a))
     g_fp.close()
     g_int.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SEAL-typical chains with primes above 2^50: the integer kernels, guarded (58..60 bits) and unguarded (51..57 bits),
+# with and without the lazy 128-bit inner product (<= 55 bits)
+# ---------------------------------------------------------------------------------------------------------------------
+WIDE_CHAINS = {
+    "60_40_40_60": [60, 40, 40, 60],      # guarded butterflies (k_fused_ks_decomp_ntt<LB,true,false>, moddown<LB,true>)
+    "57_45_45_57": [57, 45, 45, 57],      # unguarded, non-lazy inner product (<LB,false,false>, moddown<LB,false>)
+    "55_52_51_55": [55, 52, 51, 55],      # unguarded + lazy (<LB,false,true>) with every prime above the fp64 limit
+    "60_50_40_50": [60, 50, 40, 50],      # mixed: fp64-capable primes next to a 60-bit one (must not take the fp64 path)
+}
+
+
+@pytest.mark.parametrize("chain", list(WIDE_CHAINS))
+def test_ckks14_wide_prime_chains_every_level(chain, oracle_mod, capi):
+    n = 16384
+    primes = oracle_mod.create_primes(n, WIDE_CHAINS[chain])
+    o = oracle_mod.Oracle(oracle_mod.CKKS, n, primes)
+    o.keygen(0xABC00060)
+    g = capi.Context(capi.CKKS, n, primes)
+    g.load_keys(sk=o.secret_key(), pk=o.public_key(), relin=o.relin_key(),
+                galois={e: o.galois_key(e) for e in o.galois_elts()})
+    rng = np.random.default_rng(60)
+    L = len(primes) - 1
+    x = np.stack([rng.integers(0, q, size=(2, n), dtype=np.uint64) for q in primes[:L]], axis=1)
+    y = _extreme_ct(primes, L, n, rng)
+    for level in range(L, 0, -1):
+        assert x.shape[1] == level
+        _same("%s mul_relin level %d" % (chain, level), g.mul_relin(x, y), o.mul_relin(x, y))
+        _same("%s rotate level %d" % (chain, level), g.rotate(y, 3), o.rotate(y, 3))
+        _same("%s rotate (NAF) level %d" % (chain, level), g.rotate(x, 7), o.rotate(x, 7))
+        if level > 1:
+            _same("%s rescale level %d" % (chain, level), g.rescale(y), o.rescale(y))
+            both = np.stack([x, y, x])
+            _same("%s batched mul_relin level %d" % (chain, level), g.mul_relin(both, both[::-1].copy())[1], o.mul_relin(y, y))
+            x, y = o.mod_switch(x), o.mod_switch(y)
+    g.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# several chunks per lane: the hot call splits a batch into chunks that alternate over internal streams and reuse
+# per-lane scratch; every pair of a batch that spans chunk boundaries is checked, also with `out` aliasing `a`
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["default", "integer_transforms", "fp64_unsplit", "split_v1"])
+def test_multi_chunk_batches_every_pair(variant, oracle14, capi, monkeypatch):
+    import ctypes as C
+    o, primes, ins, want = oracle14
+    extra = dict(VARIANTS.get(variant, {}))
+    if variant == "split_v1":
+        extra = {"ABC_HIP_NO_SPLIT2": "1"}
+    for k, v in extra.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("ABC_HIP_CHUNK", "3")
+    monkeypatch.setenv("ABC_HIP_LANES", "2")
+    g = capi.Context(capi.CKKS, o.n, primes)
+    g.load_keys(sk=o.secret_key(), pk=o.public_key(), relin=o.relin_key(),
+                galois={e: o.galois_key(e) for e in o.galois_elts()})
+    rng = np.random.default_rng(11)
+    B = 11  # chunks of 3, 3, 3, 2 over two lanes: two chunks per lane, a ragged tail
+    pool = [ins["cx"], ins["cy"], ins["ex"], ins["ey"]]
+    a = np.stack([pool[int(i)] for i in rng.integers(0, 4, B)])
+    b = np.stack([pool[int(i)] for i in rng.integers(0, 4, B)])
+    a[5] = np.stack([rng.integers(0, q, size=(2, o.n), dtype=np.uint64) for q in primes[:4]], axis=1)
+    expect = np.stack([o.mul_relin(a[i], b[i]) for i in range(B)])
+    got = g.mul_relin(a, b)
+    for i in range(B):
+        _same("%s chunked mul_relin pair %d" % (variant, i), got[i], expect[i])
+    # out aliasing a (multiplyInplace), then out aliasing b
+    for alias in (0, 1):
+        da, db = g.upload(a), g.upload(b)
+        dst = (da, db)[alias]
+        g.op("mul_relin", da.ptr, db.ptr, dst.ptr, 4, C.c_size_t(B))
+        res = g.download(dst, a.shape)
+        for i in range(B):
+            _same("%s chunked in-place (alias %d) pair %d" % (variant, alias, i), res[i], expect[i])
+        da.free(); db.free()
+    rexp = np.stack([o.rotate(a[i], -7) for i in range(B)])
+    rgot = g.rotate(a, -7)
+    for i in range(B):
+        _same("%s chunked rotate pair %d" % (variant, i), rgot[i], rexp[i])
+    g.close()
+
+
+def test_allocator_cache_trim_and_cap(capi):
+    """alternating sizes: freed blocks are cached, abc_hip_trim returns them, a context destroyed with live buffers frees them"""
+    n = 4096
+    g = capi.Context.bfv_default(n)
+    sizes = [1 << 20, 3 << 20]
+    for rnd in range(6):
+        bufs = [g.alloc(sizes[(rnd + k) % 2]) for k in range(4)]
+        for b_ in bufs:
+            b_.free()
+    assert g.cached_bytes() == 2 * (1 << 20) + 2 * (3 << 20)  # two blocks per size were ever live at once
+    g.trim()
+    assert g.cached_bytes() == 0
+    keep = g.alloc(1 << 20)  # still live at destroy: freed by the context
+    g.close()
+    keep.ptr = None
