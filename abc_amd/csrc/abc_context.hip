@@ -208,6 +208,8 @@ static int build_context(abc_hip_ctx *c) {
     k.special_mod_q[j] = qsp % q;
     k.inv_special_c[j] = k.inv_special[j] > q / 2 ? -(double)(q - k.inv_special[j]) : (double)k.inv_special[j];
     k.inv_special_cq[j] = k.inv_special_c[j] / (double)q;
+    k.special_c[j] = k.special_mod_q[j] > q / 2 ? -(double)(q - k.special_mod_q[j]) : (double)k.special_mod_q[j];
+    k.special_cq[j] = k.special_c[j] / (double)q;
   }
   for (int l = 1; l < L; l++)
     for (int j = 0; j < l; j++) {

@@ -28,6 +28,7 @@ struct DevConst {
   u64 inv_qlast[kMaxLimbs][kMaxLimbs], inv_qlast_s[kMaxLimbs][kMaxLimbs];  // [l][j] = q_l^-1 mod q_j
   u64 special_mod_q[kMaxLimbs];
   double inv_special_c[kMaxLimbs], inv_special_cq[kMaxLimbs];  // fp64 path: centred value and value / q_j
+  double special_c[kMaxLimbs], special_cq[kMaxLimbs];          // q_special mod q_j, centred, and that / q_j
   double inv_qlast_c[kMaxLimbs][kMaxLimbs], inv_qlast_cq[kMaxLimbs][kMaxLimbs];  // same for inv_qlast (rescale)                                // q_special mod q_j (key generation)
   // BFV plaintext scaling (Evaluator::add_plain / Encryptor)
   u64 q_mod_t, upper_half_threshold, t;

@@ -748,6 +748,251 @@ __global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const 
   }
 }
 
+
+// ---- split transforms, second generation ("split2": N = 2^14, CKKS, every key prime < 2^50) ----------------------------
+// Same arithmetic as the kernels above, 84 limb transfers per multiply instead of 104 and three launches instead of four:
+//   * the tensor kernel reads only a1, b1 (c2 = a1 b1 is all the key switch needs) and writes only the half-done limbs;
+//   * the tail / inner-product kernel computes the diagonal operand c2_I = a1 b1 itself, block by block, together with
+//     c0 = a0 b0 and c1 = a0 b1 + a1 b0, and folds q_sp * c0, q_sp * c1 into the accumulators:
+//         (acc + q_sp c - NTT(t)) q_sp^-1  =  (acc - NTT(t)) q_sp^-1 + c      (mod q_I)
+//     so neither c0, c1 nor c2's NTT form ever travel through scratch (8 + 8 + 4 + 4 limbs), and `out` may still alias an
+//     operand (a and b are last read by this kernel, `out` is first written by the next one);
+//   * sums over J are formed in registers: wavefront J finishes its limb, parks it in its LDS buffer, and after one
+//     barrier every thread owns two adjacent coefficients of the block for all J (16-byte key loads, fully coalesced
+//     16-byte stores, no LDS atomics);
+//   * the workgroups of the special prime also run the ten block-local stages of its inverse transform, so the separate
+//     inverse-transform kernel is gone: the mod-down kernel starts with the remaining radix-16 pass on the sixteen
+//     stride-1024 values it loads anyway.
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_split2_tensor_pass0_fp(DevCtx c, const u64 *__restrict__ a,
+                                                                           const u64 *__restrict__ b, double *__restrict__ part,
+                                                                           int nl) {
+  static_assert(LB == 14, "split transforms are laid out for N = 2^14");
+  __shared__ double lds[lds_words(LB)];
+  const int j = blockIdx.x % nl;
+  const size_t ct = blockIdx.x / nl;
+  const size_t N = (size_t)1 << LB, pw = (size_t)nl * N;
+  double src[16];
+  {
+    const Mod m = mod_at(c, j);
+    const FpTable t = fp_table(c, j);
+    const u64 *__restrict__ a1 = a + ct * 2 * pw + pw + (size_t)j * N, *__restrict__ b1 = b + ct * 2 * pw + pw + (size_t)j * N;
+    const double q = m.qd, qinv = m.qinv;
+    ntt_inv_block_a<LB, FpArith>(
+        lds, [&](int, int i) { return fp_mulmod(fp_from_u64(a1[i]), fp_from_u64(b1[i]), q, qinv); },
+        // canonical [0, q_j) as a double: the value SEAL's decomposition reduces modulo the other primes
+        [&](int r, int, double v) {
+          const double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
+          src[r] = w < 0.0 ? w + m.qd : w;
+        },
+        t, m, 0, 0);
+  }
+  const int tid = threadIdx.x;
+  const int hi0[1] = {0};
+  for (int I = 0; I <= nl; I++) {
+    if (I == j) continue;
+    const int ki = (I == nl) ? c.K - 1 : I;
+    const Mod m = mod_at(c, ki);
+    const FpTable t = fp_table(c, ki);
+    const FpK kk = FpArith::consts(m);
+    double y[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) y[k] = src[k];
+    fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
+    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * N;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(k << 10) + tid] = y[k];
+  }
+}
+
+// MODE 0: ciphertext x ciphertext multiply (opa = a, opb = b: [ct][2][nl][N]).
+// MODE 1: key switch of an operand in NTT form at opa + ct * opa_stride (limb I = the diagonal term), optional addend
+//         (c0, c1) at opb + ct * opb_stride, c1 only if add_c1; GAL: the Galois permutation of a rotation folded into both.
+// NL > 0: compile-time limb count (the loop over J unrolls, all its loads are issued together); NL = 0: any nl <= 12.
+template <int MODE, bool GAL, int NL>
+__global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split2_tailmac_fp(DevCtx c, const double *__restrict__ part,
+                                                                          const u64 *__restrict__ opa, const u64 *__restrict__ opb,
+                                                                          size_t opa_stride, size_t opb_stride, int add_c1,
+                                                                          const u64 *__restrict__ key, u64 *__restrict__ ksacc,
+                                                                          double *__restrict__ tsp_half, int nl_rt, u32 gelt) {
+  extern __shared__ double dyn[];  // max(nl, 2) buffers of one 1024-point block each
+  const int nl = NL ? NL : nl_rt;
+  const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & 15;
+  const int I = (blockIdx.x >> 4) % (nl + 1);
+  const size_t ct = (blockIdx.x >> 4) / (nl + 1);
+  const size_t N = (size_t)c.n, base = (size_t)blk << 10;
+  const int ki = (I == nl) ? c.K - 1 : I;
+  const Mod m = mod_at(c, ki);
+  const FpTable t = fp_table(c, ki);
+  const double q = m.qd, qinv = m.qinv;
+  const bool diag = (I < nl);  // limb I of the operand is already in NTT form modulo q_I: no transform for J = I
+  if (!(diag && J == I)) {
+    double *buf = dyn + J * lds_words(10);
+    const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + base;
+    ntt_fwd_block_a<10, FpArith>(
+        buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk,
+        lane);
+  }
+  __syncthreads();
+  const double spc = diag ? c.cst->special_c[I] : 0.0, spq = diag ? c.cst->special_cq[I] : 0.0;
+  const size_t pw = (size_t)nl * N;
+  for (int e = 2 * (int)threadIdx.x; e < 1024; e += 2 * (int)blockDim.x) {  // this thread: coefficients e, e + 1 of the block
+    double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
+#pragma unroll
+    for (int Jx = 0; Jx < (NL ? NL : 12); Jx++) {
+      if (!NL && Jx >= nl) break;
+      double x[2];
+      if (diag && Jx == I) {
+        if (MODE == 0) {
+          const u64 *pa = opa + ct * 2 * pw + (size_t)I * N + base + e, *pb = opb + ct * 2 * pw + (size_t)I * N + base + e;
+          const u64x2 a0 = *reinterpret_cast<const u64x2 *>(pa), a1 = *reinterpret_cast<const u64x2 *>(pa + pw);
+          const u64x2 b0 = *reinterpret_cast<const u64x2 *>(pb), b1 = *reinterpret_cast<const u64x2 *>(pb + pw);
+          const double x0[2] = {fp_from_u64(a0.x), fp_from_u64(a0.y)}, x1[2] = {fp_from_u64(a1.x), fp_from_u64(a1.y)};
+          const double y0[2] = {fp_from_u64(b0.x), fp_from_u64(b0.y)}, y1[2] = {fp_from_u64(b1.x), fp_from_u64(b1.y)};
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            x[k] = fp_mulmod(x1[k], y1[k], q, qinv);
+            d0[k] = fp_mulmod(x0[k], y0[k], q, qinv);
+            d1[k] = fp_mulmod(x0[k], y1[k], q, qinv) + fp_mulmod(x1[k], y0[k], q, qinv);
+          }
+        } else {
+          const u64 *xl = opa + ct * opa_stride + (size_t)I * N;  // whole limb: a rotation gathers across blocks
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const u32 si = galois_ntt_src<GAL>((u32)(base + e + k), gelt, c.logn);
+            x[k] = fp_from_u64(xl[si]);
+            if (opb) {
+              const u64 *ad = opb + ct * opb_stride + (size_t)I * N;
+              d0[k] = fp_from_u64(ad[si]);
+              if (add_c1) d1[k] = fp_from_u64(ad[pw + si]);
+            }
+          }
+        }
+      } else {
+        const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
+        x[0] = v.x;
+        x[1] = v.y;
+      }
+      const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
+      const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
+      s0[0] += fp_mulmod(x[0], fp_from_u64(k0.x), q, qinv);
+      s0[1] += fp_mulmod(x[1], fp_from_u64(k0.y), q, qinv);
+      s1[0] += fp_mulmod(x[0], fp_from_u64(k1.x), q, qinv);
+      s1[1] += fp_mulmod(x[1], fp_from_u64(k1.y), q, qinv);
+      if (Jx == 7) {  // eight products of magnitude < q stay below 2^53; re-centre before adding more
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          s0[k] = fp_centre(s0[k], q, qinv);
+          s1[k] = fp_centre(s1[k], q, qinv);
+        }
+      }
+    }
+    if (diag) {
+      // + q_sp * (c0, c1): the mod-down's division by q_sp turns it into + (c0, c1)
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        s0[k] += fp_mul_lazy(d0[k], spc, spq, q);
+        s1[k] += fp_mul_lazy(d1[k], spc, spq, q);
+      }
+      u64x2 r;
+      r.x = fp_to_canon(s0[0], q, qinv); r.y = fp_to_canon(s0[1], q, qinv);
+      *reinterpret_cast<u64x2 *>(ksacc + ((ct * 2 + 0) * nl + I) * N + base + e) = r;
+      r.x = fp_to_canon(s1[0], q, qinv); r.y = fp_to_canon(s1[1], q, qinv);
+      *reinterpret_cast<u64x2 *>(ksacc + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
+    } else {
+      // special prime: park the two sums (centred) in buffers 0 and 1; this thread has read its words of them already
+      f64x2 r;
+      r.x = fp_centre(s0[0], q, qinv); r.y = fp_centre(s0[1], q, qinv);
+      *reinterpret_cast<f64x2 *>(dyn + lds_pad(e)) = r;
+      r.x = fp_centre(s1[0], q, qinv); r.y = fp_centre(s1[1], q, qinv);
+      *reinterpret_cast<f64x2 *>(dyn + lds_words(10) + lds_pad(e)) = r;
+    }
+  }
+  if (!diag) {  // workgroup-uniform
+    __syncthreads();
+    // stages 13..4 of the special-prime limb's inverse transform on this block, one wavefront per component
+    for (int comp = J; comp < 2; comp += nl) {
+      double *buf = dyn + comp * lds_words(10);
+      double *__restrict__ dst = tsp_half + (ct * 2 + comp) * N + base;
+      ntt_inv_block_a<10, FpArith>(
+          buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, 4, blk, lane);
+    }
+  }
+}
+
+// mod-down: the last radix-16 pass of the special-prime limb's inverse transform on the sixteen stride-1024 values of a
+// lane, N^-1, + q_sp/2, canonical; then (as k_fused_ks_moddown_fp) the forward transform modulo q_j in LDS, subtract,
+// scale by q_sp^-1.  No addend: the tail kernel has folded it into the accumulators.
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_split2_moddown_fp(DevCtx c, const u64 *__restrict__ ksacc,
+                                                                      const double *__restrict__ tsp_half, u64 *__restrict__ out,
+                                                                      int nl, int ncc) {
+  static_assert(LB == 14, "split transforms are laid out for N = 2^14");
+  __shared__ double lds[lds_words(LB)];
+  // the nl workgroups that read one special-prime polynomial are 8 apart in blockIdx: they share an XCD's L2
+  const unsigned per = 8u * (unsigned)nl;
+  const unsigned grp = blockIdx.x / per, rem = blockIdx.x % per;
+  const unsigned left = (unsigned)ncc - grp * 8u, gsz = left < 8u ? left : 8u;  // the last group may be ragged
+  const int j = (int)(rem / gsz);
+  const size_t cc = (size_t)grp * 8 + rem % gsz;  // ct*2 + comp
+  const size_t N = (size_t)1 << LB;
+  const int tid = threadIdx.x;
+  double x[16];
+  {
+    const Mod ms = mod_at(c, c.K - 1);
+    const FpTable ts = fp_table(c, c.K - 1);
+    const FpK ks = FpArith::consts(ms);
+    const double *__restrict__ src = tsp_half + cc * N;
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = src[(k << 10) + tid];
+    FpArith::centre16(x, ks);
+    const int hi0[1] = {0};
+    inv_pass<FpArith, LB, 0, 4>(x, hi0, ts, ks, 0, 0);
+    const double half = (double)(ms.q >> 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const double w = fp_centre(fp_mul_lazy(x[k], ms.inv_n_c, ms.inv_n_cq, ms.qd) + half, ms.qd, ms.qinv);
+      x[k] = w < 0.0 ? w + ms.qd : w;  // canonical [0, q_sp): what SEAL reduces modulo q_j
+    }
+  }
+  const Mod m = mod_at(c, j);
+  const FpTable t = fp_table(c, j);
+  const u64 half = c.mods[c.K - 1].q >> 1;
+  const u64 hm = reduce64(half, m);
+  const double fix = hm ? (double)(m.q - hm) : 0.0;
+  const double inv = c.cst->inv_special_c[j], inv_q = c.cst->inv_special_cq[j];
+  const u64 *__restrict__ ks = ksacc + (cc * nl + j) * N;
+  u64 *__restrict__ o = out + (cc * nl + j) * N;
+  ntt_fwd_block_a<LB, FpArith>(
+      lds, [&](int r, int) { return x[r] + fix; },
+      [&](int, int i, double v) {
+        const double d = fp_from_u64(ks[i]) - v;
+        o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd), m.qd, m.qinv);
+      },
+      t, m, 0, 0);
+}
+
+template <int MODE, bool GAL>
+static void launch_split2_tailmac(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const u64 *opa, const u64 *opb,
+                                  size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *ksacc, double *tsp_half,
+                                  u32 gelt) {
+  const dim3 grid((unsigned)(cc * (nl + 1) * 16)), block(64 * nl);
+  const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
+#define ABC_TM2(NLV)                                                                                                            \
+  hipLaunchKernelGGL((k_split2_tailmac_fp<MODE, GAL, NLV>), grid, block, lds, st, c->dc, part, opa, opb, opa_stride, opb_stride, \
+                     add_c1, key, ksacc, tsp_half, nl, gelt)
+  switch (nl) {
+    case 1: ABC_TM2(1); break;
+    case 2: ABC_TM2(2); break;
+    case 3: ABC_TM2(3); break;
+    case 4: ABC_TM2(4); break;
+    default: ABC_TM2(0); break;
+  }
+#undef ABC_TM2
+}
+
 // scratch limbs per ciphertext: coef L, ntt L, dec L(L+1), ksacc 2L, tsp 2, tlast 2, c01 2L
 static inline size_t fused_scratch_limbs(int nl) { return (size_t)nl * (nl + 1) + 6 * (size_t)nl + 4; }
 
@@ -929,6 +1174,16 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
     bool split = false;
     if constexpr (LB == 14) split = fuse_decomp && !c->sw.no_split;
     if constexpr (LB == 14) {
+      if (split && !c->sw.no_split2 && nl <= 12) {  // second-generation split kernels: three launches, 84 limb transfers
+        hipLaunchKernelGGL(k_split2_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
+                           b + off * ctw, (double *)s.dec, nl);
+        launch_split2_tailmac<0, false>(st, c, cc, nl, (const double *)s.dec, a + off * ctw, b + off * ctw, 0, 0, 0, c->d_relin,
+                                        s.ksacc, (double *)s.tsp, 0u);
+        hipLaunchKernelGGL(k_split2_moddown_fp<LB>, dim3((unsigned)(cc * 2 * nl)), dim3((1 << LB) / 16), 0, st, c->dc, s.ksacc,
+                           (const double *)s.tsp, out + off * ctw, nl, (int)(cc * 2));
+        ABC_HIP_CHECK(hipGetLastError());
+        continue;
+      }
       if (split)
         hipLaunchKernelGGL(k_fused_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
                            b + off * ctw, s.c01, s.ntt, (double *)s.dec, nl);
@@ -999,6 +1254,21 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
       else if (split)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
                            target_stride, (double *)s.dec, nl, 0, 0u);
+    }
+    if constexpr (LB == 14) {
+      if (split && ckks && !c->sw.no_split2 && nl <= 12) {
+        const u64 *ad = addend ? addend + off * addend_stride : nullptr;
+        if (gelt)
+          launch_split2_tailmac<1, true>(st, c, cc, nl, (const double *)s.dec, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key,
+                                         s.ksacc, (double *)s.tsp, gelt);
+        else
+          launch_split2_tailmac<1, false>(st, c, cc, nl, (const double *)s.dec, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key,
+                                          s.ksacc, (double *)s.tsp, 0u);
+        hipLaunchKernelGGL(k_split2_moddown_fp<LB>, dim3((unsigned)(cc * 2 * nl)), dim3((1 << LB) / 16), 0, st, c->dc, s.ksacc,
+                           (const double *)s.tsp, out + off * 2 * nl * N, nl, (int)(cc * 2));
+        ABC_HIP_CHECK(hipGetLastError());
+        continue;
+      }
     }
     if (split) {
     } else if (ckks) {  // operand arrives in NTT form: coefficient form via one in-LDS inverse transform per limb

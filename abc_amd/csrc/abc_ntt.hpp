@@ -379,9 +379,11 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
 //                              for a sub-block the scaling belongs to the final strided pass)
 template <int LB, class A, class Load, class Store>
 __device__ __forceinline__ void ntt_inv_block_a(typename A::E *lds, Load load, Store store, const typename A::Table &t,
-                                                const Mod &m, int S0, int b) {
+                                                const Mod &m, int S0, int b, int tid_in = -1) {
   using SC = Sched<LB>;
-  const int tid = threadIdx.x;
+  // as in the forward transform: a 1024-point block is one wavefront (tid_in = the lane id), nothing in it may then be a
+  // workgroup barrier
+  const int tid = tid_in < 0 ? (int)threadIdx.x : tid_in;
   const typename A::K kk = A::consts(m);
   typename A::E x[16];
   constexpr int SA = SC::R0, SB = SC::R0 + SC::R1, SCc = SC::R0 + SC::R1 + SC::R2;
@@ -426,7 +428,7 @@ __device__ __forceinline__ void ntt_inv_block_a(typename A::E *lds, Load load, S
     A::template inv_begin<(SC::R3 != 0 ? 2 : 1)>(x, kk);
     inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
-    block_sync_lds();
+    if constexpr (LB <= 10) wave_sync(); else block_sync_lds();
   }
   {
     constexpr int S = 0, R = SC::R0;
