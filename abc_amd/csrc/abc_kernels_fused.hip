@@ -814,14 +814,16 @@ __global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split2_tailmac_fp(DevCtx
                                                                           const u64 *__restrict__ opa, const u64 *__restrict__ opb,
                                                                           size_t opa_stride, size_t opb_stride, int add_c1,
                                                                           const u64 *__restrict__ key, u64 *__restrict__ ksacc,
-                                                                          double *__restrict__ tsp_half, int nl_rt, u32 gelt) {
+                                                                          double *__restrict__ tsp_half, int nl_rt, u32 gelt,
+                                                                          int only_special) {
   extern __shared__ double dyn[];  // max(nl, 2) buffers of one 1024-point block each
   const int nl = NL ? NL : nl_rt;
   const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int blk = blockIdx.x & 15;
-  const int I = (blockIdx.x >> 4) % (nl + 1);
-  const size_t ct = (blockIdx.x >> 4) / (nl + 1);
+  // only_special (split3): grid = (ct, block), every workgroup works modulo the special prime
+  const int I = only_special ? nl : (int)((blockIdx.x >> 4) % (nl + 1));
+  const size_t ct = only_special ? (size_t)(blockIdx.x >> 4) : (size_t)((blockIdx.x >> 4) / (nl + 1));
   const size_t N = (size_t)c.n, base = (size_t)blk << 10;
   const int ki = (I == nl) ? c.K - 1 : I;
   const Mod m = mod_at(c, ki);
@@ -977,12 +979,12 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_split2_moddown_fp(DevCtx c, 
 template <int MODE, bool GAL>
 static void launch_split2_tailmac(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const u64 *opa, const u64 *opb,
                                   size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *ksacc, double *tsp_half,
-                                  u32 gelt) {
-  const dim3 grid((unsigned)(cc * (nl + 1) * 16)), block(64 * nl);
+                                  u32 gelt, int only_special = 0) {
+  const dim3 grid((unsigned)(cc * (only_special ? 1 : nl + 1) * 16)), block(64 * nl);
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
 #define ABC_TM2(NLV)                                                                                                            \
   hipLaunchKernelGGL((k_split2_tailmac_fp<MODE, GAL, NLV>), grid, block, lds, st, c->dc, part, opa, opb, opa_stride, opb_stride, \
-                     add_c1, key, ksacc, tsp_half, nl, gelt)
+                     add_c1, key, ksacc, tsp_half, nl, gelt, only_special)
   switch (nl) {
     case 1: ABC_TM2(1); break;
     case 2: ABC_TM2(2); break;
@@ -1009,6 +1011,188 @@ static inline FusedScratch carve(u64 *base, size_t chunk, int nl, size_t N) {
   s.tlast = s.tsp + chunk * 2 * N;
   s.c01 = s.tlast + chunk * 2 * N;
   return s;
+}
+
+
+// ---- third generation ("split3"): the mod-down moves into the tail kernel, no LDS-resident kernel after the first one ----
+//   K1  k_split2_tensor_pass0_fp / k_fused_operand_pass0_fp            (unchanged)
+//   K2a k_split2_tailmac_fp, special prime only: inner product modulo q_sp and the block-local part of its inverse transform
+//   K2b k_split3_pass_fp: per (ct, component), registers only: last radix-16 pass of that inverse transform, N^-1, + q_sp/2,
+//       then for every data prime q_j the first radix-16 pass of the forward transform of (t mod q_j): half-done limbs
+//   K2c k_split3_main_fp, per (ct, data prime I, block): nl - 1 wavefronts finish the decomposition limbs, two more finish the
+//       two half-done mod-down limbs of K2b on the same block, then every thread forms, for two adjacent coefficients,
+//           out_c = (sum_J x_J key_J,c + q_sp c_c - NTT_I(t_c))  q_sp^-1                                  (mod q_I)
+//       and stores the result: the accumulators never leave the CU (8 + 8 limbs), and the 139 KiB mod-down workgroups,
+//       whose load / compute / store phases did not overlap at all (T = T_HBM + T_VALU), are gone.
+template <int LB>
+__global__ __launch_bounds__(256) void k_split3_pass_fp(DevCtx c, const double *__restrict__ tsp_half, double *__restrict__ tpart, int nl) {
+  static_assert(LB == 14, "split transforms are laid out for N = 2^14");
+  const size_t N = (size_t)1 << LB;
+  const size_t cc = blockIdx.x >> 2;                                  // ct*2 + comp
+  const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;      // position inside every 1024-point block
+  const int hi0[1] = {0};
+  double x[16];
+  {
+    const Mod ms = mod_at(c, c.K - 1);
+    const FpTable ts = fp_table(c, c.K - 1);
+    const FpK ks = FpArith::consts(ms);
+    const double *__restrict__ src = tsp_half + cc * N;
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = src[(k << 10) + p];
+    FpArith::centre16(x, ks);
+    inv_pass<FpArith, LB, 0, 4>(x, hi0, ts, ks, 0, 0);
+    const double half = (double)(ms.q >> 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const double w = fp_centre(fp_mul_lazy(x[k], ms.inv_n_c, ms.inv_n_cq, ms.qd) + half, ms.qd, ms.qinv);
+      x[k] = w < 0.0 ? w + ms.qd : w;  // canonical [0, q_sp): what SEAL reduces modulo q_j
+    }
+  }
+  const u64 half = c.mods[c.K - 1].q >> 1;
+  for (int j = 0; j < nl; j++) {
+    const Mod m = mod_at(c, j);
+    const FpTable t = fp_table(c, j);
+    const FpK kk = FpArith::consts(m);
+    const u64 hm = reduce64(half, m);
+    const double fix = hm ? (double)(m.q - hm) : 0.0;
+    double y[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) y[k] = x[k] + fix;
+    fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
+    double *__restrict__ dst = tpart + (cc * nl + j) * N;
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(k << 10) + p] = y[k];
+  }
+}
+
+template <int MODE, bool GAL, int NL>
+__global__ __launch_bounds__(NL ? (NL + 1) * 64 : 832) void k_split3_main_fp(DevCtx c, const double *__restrict__ part,
+                                                                              const double *__restrict__ tpart,
+                                                                              const u64 *__restrict__ opa, const u64 *__restrict__ opb,
+                                                                              size_t opa_stride, size_t opb_stride, int add_c1,
+                                                                              const u64 *__restrict__ key, u64 *__restrict__ out, int nl_rt,
+                                                                              u32 gelt) {
+  extern __shared__ double dyn[];  // nl + 1 buffers of one 1024-point block: nl - 1 decomposition limbs, 2 mod-down limbs
+  const int nl = NL ? NL : nl_rt;
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & 15;
+  const int I = (int)((blockIdx.x >> 4) % nl);
+  const size_t ct = (size_t)((blockIdx.x >> 4) / nl);
+  const size_t N = (size_t)c.n, base = (size_t)blk << 10;
+  const Mod m = mod_at(c, I);
+  const FpTable t = fp_table(c, I);
+  const double q = m.qd, qinv = m.qinv;
+  {
+    double *buf = dyn + W * lds_words(10);
+    const double *__restrict__ src;
+    if (W < nl - 1) {
+      const int J = W < I ? W : W + 1;
+      src = part + ((ct * (nl + 1) + I) * nl + J) * N + base;
+    } else {
+      src = tpart + ((ct * 2 + (W - (nl - 1))) * nl + I) * N + base;
+    }
+    ntt_fwd_block_a<10, FpArith>(
+        buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk,
+        lane);
+  }
+  __syncthreads();
+  const double spc = c.cst->special_c[I], spq = c.cst->special_cq[I];
+  const double inv = c.cst->inv_special_c[I], inv_q = c.cst->inv_special_cq[I];
+  const size_t pw = (size_t)nl * N;
+  const double *tt0 = dyn + (nl - 1) * lds_words(10), *tt1 = dyn + nl * lds_words(10);
+  for (int e = 2 * (int)threadIdx.x; e < 1024; e += 2 * (int)blockDim.x) {  // this thread: coefficients e, e + 1 of the block
+    double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
+#pragma unroll
+    for (int Jx = 0; Jx < (NL ? NL : 12); Jx++) {
+      if (!NL && Jx >= nl) break;
+      double x[2];
+      if (Jx == I) {
+        if (MODE == 0) {
+          const u64 *pa = opa + ct * 2 * pw + (size_t)I * N + base + e, *pb = opb + ct * 2 * pw + (size_t)I * N + base + e;
+          const u64x2 a0 = *reinterpret_cast<const u64x2 *>(pa), a1 = *reinterpret_cast<const u64x2 *>(pa + pw);
+          const u64x2 b0 = *reinterpret_cast<const u64x2 *>(pb), b1 = *reinterpret_cast<const u64x2 *>(pb + pw);
+          const double x0[2] = {fp_from_u64(a0.x), fp_from_u64(a0.y)}, x1[2] = {fp_from_u64(a1.x), fp_from_u64(a1.y)};
+          const double y0[2] = {fp_from_u64(b0.x), fp_from_u64(b0.y)}, y1[2] = {fp_from_u64(b1.x), fp_from_u64(b1.y)};
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            x[k] = fp_mulmod(x1[k], y1[k], q, qinv);
+            d0[k] = fp_mulmod(x0[k], y0[k], q, qinv);
+            d1[k] = fp_mulmod(x0[k], y1[k], q, qinv) + fp_mulmod(x1[k], y0[k], q, qinv);
+          }
+        } else {
+          const u64 *xl = opa + ct * opa_stride + (size_t)I * N;  // whole limb: a rotation gathers across blocks
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const u32 si = galois_ntt_src<GAL>((u32)(base + e + k), gelt, c.logn);
+            x[k] = fp_from_u64(xl[si]);
+            if (opb) {
+              const u64 *ad = opb + ct * opb_stride + (size_t)I * N;
+              d0[k] = fp_from_u64(ad[si]);
+              if (add_c1) d1[k] = fp_from_u64(ad[pw + si]);
+            }
+          }
+        }
+      } else {
+        const int w = Jx < I ? Jx : Jx - 1;
+        const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + w * lds_words(10) + lds_pad(e));
+        x[0] = v.x;
+        x[1] = v.y;
+      }
+      const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + I) * N + base + e);
+      const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + I) * N + base + e);
+      s0[0] += fp_mulmod(x[0], fp_from_u64(k0.x), q, qinv);
+      s0[1] += fp_mulmod(x[1], fp_from_u64(k0.y), q, qinv);
+      s1[0] += fp_mulmod(x[0], fp_from_u64(k1.x), q, qinv);
+      s1[1] += fp_mulmod(x[1], fp_from_u64(k1.y), q, qinv);
+      if (Jx == 7) {  // eight products of magnitude < q stay below 2^53; re-centre before adding more
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          s0[k] = fp_centre(s0[k], q, qinv);
+          s1[k] = fp_centre(s1[k], q, qinv);
+        }
+      }
+    }
+    const f64x2 u0 = *reinterpret_cast<const f64x2 *>(tt0 + lds_pad(e)), u1 = *reinterpret_cast<const f64x2 *>(tt1 + lds_pad(e));
+    // (sum + q_sp (c0, c1) - NTT(t)) q_sp^-1
+    u64x2 r;
+    r.x = fp_to_canon(fp_mul_lazy(s0[0] + fp_mul_lazy(d0[0], spc, spq, q) - u0.x, inv, inv_q, q), q, qinv);
+    r.y = fp_to_canon(fp_mul_lazy(s0[1] + fp_mul_lazy(d0[1], spc, spq, q) - u0.y, inv, inv_q, q), q, qinv);
+    *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 0) * nl + I) * N + base + e) = r;
+    r.x = fp_to_canon(fp_mul_lazy(s1[0] + fp_mul_lazy(d1[0], spc, spq, q) - u1.x, inv, inv_q, q), q, qinv);
+    r.y = fp_to_canon(fp_mul_lazy(s1[1] + fp_mul_lazy(d1[1], spc, spq, q) - u1.y, inv, inv_q, q), q, qinv);
+    *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
+  }
+}
+
+template <int MODE, bool GAL>
+static void launch_split3_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const double *tpart, const u64 *opa,
+                               const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt) {
+  const dim3 grid((unsigned)(cc * nl * 16)), block(64 * (nl + 1));
+  const size_t lds = (size_t)((nl + 1) * lds_words(10)) * 8;
+#define ABC_TM3(NLV)                                                                                                                 \
+  hipLaunchKernelGGL((k_split3_main_fp<MODE, GAL, NLV>), grid, block, lds, st, c->dc, part, tpart, opa, opb, opa_stride, opb_stride, \
+                     add_c1, key, out, nl, gelt)
+  switch (nl) {
+    case 1: ABC_TM3(1); break;
+    case 2: ABC_TM3(2); break;
+    case 3: ABC_TM3(3); break;
+    case 4: ABC_TM3(4); break;
+    default: ABC_TM3(0); break;
+  }
+#undef ABC_TM3
+}
+
+// K2a..K2c on one chunk (the half-done decomposition limbs are in s.dec)
+template <int MODE, bool GAL>
+static void launch_split3(hipStream_t st, abc_hip_ctx *c, const FusedScratch &s, size_t cc, int nl, const u64 *opa, const u64 *opb,
+                          size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt) {
+  launch_split2_tailmac<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, opa, opb, opa_stride, opb_stride, add_c1, key, s.ksacc,
+                                   (double *)s.tsp, gelt, 1);
+  hipLaunchKernelGGL(k_split3_pass_fp<14>, dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, (const double *)s.tsp, (double *)s.ksacc,
+                     nl);
+  launch_split3_main<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, (const double *)s.ksacc, opa, opb, opa_stride, opb_stride, add_c1,
+                                key, out, gelt);
 }
 
 static inline bool all_fp(const abc_hip_ctx *c) {  // fp64 transforms: every key prime below 2^50
@@ -1177,6 +1361,11 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
       if (split && !c->sw.no_split2 && nl <= 12) {  // second-generation split kernels: three launches, 84 limb transfers
         hipLaunchKernelGGL(k_split2_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
                            b + off * ctw, (double *)s.dec, nl);
+        if (!c->sw.no_split3) {
+          launch_split3<0, false>(st, c, s, cc, nl, a + off * ctw, b + off * ctw, 0, 0, 0, c->d_relin, out + off * ctw, 0u);
+          ABC_HIP_CHECK(hipGetLastError());
+          continue;
+        }
         launch_split2_tailmac<0, false>(st, c, cc, nl, (const double *)s.dec, a + off * ctw, b + off * ctw, 0, 0, 0, c->d_relin,
                                         s.ksacc, (double *)s.tsp, 0u);
         hipLaunchKernelGGL(k_split2_moddown_fp<LB>, dim3((unsigned)(cc * 2 * nl)), dim3((1 << LB) / 16), 0, st, c->dc, s.ksacc,
@@ -1258,6 +1447,14 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     if constexpr (LB == 14) {
       if (split && ckks && !c->sw.no_split2 && nl <= 12) {
         const u64 *ad = addend ? addend + off * addend_stride : nullptr;
+        if (!c->sw.no_split3) {
+          if (gelt)
+            launch_split3<1, true>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, out + off * 2 * nl * N, gelt);
+          else
+            launch_split3<1, false>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, out + off * 2 * nl * N, 0u);
+          ABC_HIP_CHECK(hipGetLastError());
+          continue;
+        }
         if (gelt)
           launch_split2_tailmac<1, true>(st, c, cc, nl, (const double *)s.dec, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key,
                                          s.ksacc, (double *)s.tsp, gelt);
