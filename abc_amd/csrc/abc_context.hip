@@ -29,6 +29,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_split = env_on("ABC_HIP_NO_SPLIT");
   s.no_split2 = env_on("ABC_HIP_NO_SPLIT2");
   s.no_split3 = env_on("ABC_HIP_NO_SPLIT3");
+  s.no_split4 = env_on("ABC_HIP_NO_SPLIT4");
   s.no_tensor_decomp = env_on("ABC_HIP_NO_TENSOR_DECOMP");
   s.no_tensor_intt = env_on("ABC_HIP_NO_TENSOR_INTT");
   s.tailmac_serial = env_on("ABC_HIP_TAILMAC_SERIAL");

@@ -1183,6 +1183,168 @@ static void launch_split3_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
 #undef ABC_TM3
 }
 
+
+// ---- "split4": K2c with every vector-memory request issued up front ----------------------------------------------------------
+// Same arithmetic and the same buffers as k_split3_main_fp.  What changes is the order of memory requests inside a wavefront:
+// the per-lane twiddles of the tail transform come from an LDS table of the block's own twiddles (16 KiB per workgroup, filled
+// cooperatively) instead of vector loads, so nothing in the transform touches the in-order vector-memory counter any more and
+// the operands of the phase AFTER the transform (key slices, a and b) can be requested before it: one exposed memory latency per
+// workgroup instead of two, and the transform runs under the second one.
+template <int MODE, int NL>
+struct PairOps {
+  u64x2 k0[NL], k1[NL];
+  u64x2 a0, a1, b0, b1;      // MODE 0
+  u64 xs[2], d0s[2], d1s[2];  // MODE 1
+};
+
+template <int MODE, bool GAL, int NL>
+__global__ __launch_bounds__(512, 2) void k_split4_main_fp(DevCtx c, const double *__restrict__ part,
+                                                                   const double *__restrict__ tpart, const u64 *__restrict__ opa,
+                                                                   const u64 *__restrict__ opb, size_t opa_stride, size_t opb_stride,
+                                                                   int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out, u32 gelt) {
+  extern __shared__ double dyn[];  // nl + 1 transform buffers, then the block's twiddle table (1024 {w, w/q} pairs)
+  // 512 threads whatever nl: one coefficient pair per thread afterwards, so every operand of that phase is requested up front;
+  // wavefronts nl + 1 .. 7 have no limb to transform and only take part in the table fill and the inner product
+  static_assert(NL + 1 <= 8, "one wavefront per limb, eight wavefronts");
+  constexpr int nl = NL, NT = 512, PER = 2;
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & 15;
+  const int I = (int)((blockIdx.x >> 4) % nl);
+  const size_t ct = (size_t)((blockIdx.x >> 4) / nl);
+  const size_t N = (size_t)c.n, base = (size_t)blk << 10;
+  const Mod m = mod_at(c, I);
+  const FpTable t = fp_table(c, I);
+  const double q = m.qd, qinv = m.qinv;
+  f64x2 *ltw = reinterpret_cast<f64x2 *>(dyn + (nl + 1) * lds_words(10));
+  const size_t pw = (size_t)nl * N;
+  // scalar loads (constant address space): a vector load of these after the transform would expose one more memory latency
+  const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
+  const double spc = cst->special_c[I], spq = cst->special_cq[I];
+  const double inv = cst->inv_special_c[I], inv_q = cst->inv_special_cq[I];
+
+  // (1) twiddle table, (2) this wavefront's half-done limb, (3) the operands of this thread's first coefficient pair
+  f64x2 twv[PER];
+  block_twiddles_fetch<10, f64x2, PER>(t.tw, 4, blk, (int)threadIdx.x, NT, twv);
+  const bool has_limb = W <= nl;  // wavefront-uniform
+  const int Wc = has_limb ? W : 0;
+  const double *__restrict__ src = (Wc < nl - 1) ? part + ((ct * (nl + 1) + I) * nl + (Wc < I ? Wc : Wc + 1)) * N + base
+                                                 : tpart + ((ct * 2 + (Wc - (nl - 1))) * nl + I) * N + base;
+  double xin[16];
+  if (has_limb) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) xin[k] = src[(k << 6) + lane];  // PassIdx<10, 0, 4>: slot k = element (k << 6) + lane
+  }
+  auto load_pair = [&](int e, PairOps<MODE, NL> &o) {
+#pragma unroll
+    for (int Jx = 0; Jx < NL; Jx++) {
+      o.k0[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + I) * N + base + e);
+      o.k1[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + I) * N + base + e);
+    }
+    if (MODE == 0) {
+      const u64 *pa = opa + ct * 2 * pw + (size_t)I * N + base + e, *pb = opb + ct * 2 * pw + (size_t)I * N + base + e;
+      o.a0 = *reinterpret_cast<const u64x2 *>(pa); o.a1 = *reinterpret_cast<const u64x2 *>(pa + pw);
+      o.b0 = *reinterpret_cast<const u64x2 *>(pb); o.b1 = *reinterpret_cast<const u64x2 *>(pb + pw);
+    } else {
+      const u64 *xl = opa + ct * opa_stride + (size_t)I * N;  // whole limb: a rotation gathers across blocks
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const u32 si = galois_ntt_src<GAL>((u32)(base + e + k), gelt, c.logn);
+        o.xs[k] = xl[si];
+        o.d0s[k] = o.d1s[k] = 0;
+        if (opb) {
+          const u64 *ad = opb + ct * opb_stride + (size_t)I * N;
+          o.d0s[k] = ad[si];
+          if (add_c1) o.d1s[k] = ad[pw + si];
+        }
+      }
+    }
+  };
+  PairOps<MODE, NL> ops;
+  load_pair(2 * (int)threadIdx.x, ops);
+
+  block_twiddles_store<10, f64x2, PER>(ltw, (int)threadIdx.x, NT, twv);
+  __syncthreads();
+  if (has_limb) {
+    double *buf = dyn + W * lds_words(10);
+    auto ld = [&](int r, int) { return fp_centre(xin[r], q, qinv); };
+    auto st = [&](int, int i, double v) { buf[lds_pad(i)] = v; };
+    ntt_fwd_block_a<10, FpArith, decltype(ld), decltype(st), true>(buf, ld, st, t, m, 4, blk, lane, ltw);
+  }
+  __syncthreads();
+  const double *tt0 = dyn + (nl - 1) * lds_words(10), *tt1 = dyn + nl * lds_words(10);
+  auto compute_pair = [&](int e, const PairOps<MODE, NL> &o) {
+    double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
+#pragma unroll
+    for (int Jx = 0; Jx < NL; Jx++) {
+      double x[2];
+      if (Jx == I) {
+        if (MODE == 0) {
+          const double x0[2] = {fp_from_u64(o.a0.x), fp_from_u64(o.a0.y)}, x1[2] = {fp_from_u64(o.a1.x), fp_from_u64(o.a1.y)};
+          const double y0[2] = {fp_from_u64(o.b0.x), fp_from_u64(o.b0.y)}, y1[2] = {fp_from_u64(o.b1.x), fp_from_u64(o.b1.y)};
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            x[k] = fp_mulmod(x1[k], y1[k], q, qinv);
+            d0[k] = fp_mulmod(x0[k], y0[k], q, qinv);
+            d1[k] = fp_mulmod(x0[k], y1[k], q, qinv) + fp_mulmod(x1[k], y0[k], q, qinv);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            x[k] = fp_from_u64(o.xs[k]);
+            d0[k] = fp_from_u64(o.d0s[k]);
+            d1[k] = fp_from_u64(o.d1s[k]);
+          }
+        }
+      } else {
+        const int w = Jx < I ? Jx : Jx - 1;
+        const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + w * lds_words(10) + lds_pad(e));
+        x[0] = v.x;
+        x[1] = v.y;
+      }
+      s0[0] += fp_mulmod(x[0], fp_from_u64(o.k0[Jx].x), q, qinv);
+      s0[1] += fp_mulmod(x[1], fp_from_u64(o.k0[Jx].y), q, qinv);
+      s1[0] += fp_mulmod(x[0], fp_from_u64(o.k1[Jx].x), q, qinv);
+      s1[1] += fp_mulmod(x[1], fp_from_u64(o.k1[Jx].y), q, qinv);
+      if (Jx == 7) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          s0[k] = fp_centre(s0[k], q, qinv);
+          s1[k] = fp_centre(s1[k], q, qinv);
+        }
+      }
+    }
+    const f64x2 u0 = *reinterpret_cast<const f64x2 *>(tt0 + lds_pad(e)), u1 = *reinterpret_cast<const f64x2 *>(tt1 + lds_pad(e));
+    u64x2 r;
+    r.x = fp_to_canon(fp_mul_lazy(s0[0] + fp_mul_lazy(d0[0], spc, spq, q) - u0.x, inv, inv_q, q), q, qinv);
+    r.y = fp_to_canon(fp_mul_lazy(s0[1] + fp_mul_lazy(d0[1], spc, spq, q) - u0.y, inv, inv_q, q), q, qinv);
+    *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 0) * nl + I) * N + base + e) = r;
+    r.x = fp_to_canon(fp_mul_lazy(s1[0] + fp_mul_lazy(d1[0], spc, spq, q) - u1.x, inv, inv_q, q), q, qinv);
+    r.y = fp_to_canon(fp_mul_lazy(s1[1] + fp_mul_lazy(d1[1], spc, spq, q) - u1.y, inv, inv_q, q), q, qinv);
+    *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
+  };
+  compute_pair(2 * (int)threadIdx.x, ops);
+}
+
+template <int MODE, bool GAL>
+static bool launch_split4_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const double *tpart, const u64 *opa,
+                               const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt) {
+  if (nl < 1 || nl > 4) return false;
+  const dim3 grid((unsigned)(cc * nl * 16)), block(512);
+  const size_t lds = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
+#define ABC_TM4(NLV)                                                                                                                 \
+  hipLaunchKernelGGL((k_split4_main_fp<MODE, GAL, NLV>), grid, block, lds, st, c->dc, part, tpart, opa, opb, opa_stride, opb_stride, \
+                     add_c1, key, out, gelt)
+  switch (nl) {
+    case 1: ABC_TM4(1); break;
+    case 2: ABC_TM4(2); break;
+    case 3: ABC_TM4(3); break;
+    default: ABC_TM4(4); break;
+  }
+#undef ABC_TM4
+  return true;
+}
+
 // K2a..K2c on one chunk (the half-done decomposition limbs are in s.dec)
 template <int MODE, bool GAL>
 static void launch_split3(hipStream_t st, abc_hip_ctx *c, const FusedScratch &s, size_t cc, int nl, const u64 *opa, const u64 *opb,
@@ -1191,6 +1353,9 @@ static void launch_split3(hipStream_t st, abc_hip_ctx *c, const FusedScratch &s,
                                    (double *)s.tsp, gelt, 1);
   hipLaunchKernelGGL(k_split3_pass_fp<14>, dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, (const double *)s.tsp, (double *)s.ksacc,
                      nl);
+  if (!c->sw.no_split4 && launch_split4_main<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, (const double *)s.ksacc, opa, opb,
+                                                        opa_stride, opb_stride, add_c1, key, out, gelt))
+    return;
   launch_split3_main<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, (const double *)s.ksacc, opa, opb, opa_stride, opb_stride, add_c1,
                                 key, out, gelt);
 }

@@ -192,6 +192,52 @@ __device__ __forceinline__ void fwd_pass(typename A::E (&x)[16], const int (&hi)
   }
 }
 
+// The same pass with its twiddles in an LDS table of the BLOCK's own twiddles: entry 2^s + i = twiddle i of block-local stage s
+// (global index (2^S0 + b) 2^s + i; block_twiddles_to_lds below fills it).  For the passes whose twiddle index differs from
+// lane to lane: read through LDS they stay off the vector-memory counter, which on gfx950 is in order across loads AND
+// stores -- a per-lane twiddle fetched by a vector load waits for every load issued before it, so operands of a LATER phase
+// could never be requested ahead of the transform.
+template <class A, int LB, int S, int R>
+__device__ __forceinline__ void fwd_pass_lds(typename A::E (&x)[16], const int (&hi)[16 >> R], const typename A::TW *ltw,
+                                             const typename A::K &kk) {
+  constexpr int NG = 16 >> R;
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      int base = (1 << (S + u)) + (hi[g] << u);
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) {
+        if (k & half) continue;
+        int idx = base + (k >> (R - u));
+        A::fwd(x[g * (1 << R) + k], x[g * (1 << R) + (k | half)], ltw[idx], kk);
+      }
+    }
+  }
+}
+// workgroup-cooperative fill of that table for the 2^LB-point block b behind S0 strided stages: values first (vector loads,
+// issue early), then the LDS writes (call after whatever else should be requested first)
+template <int LB, class TW, int PER>
+__device__ __forceinline__ void block_twiddles_fetch(const ABC_CONST_AS TW *tw, int S0, int b, int tid, int nthreads, TW (&v)[PER]) {
+#pragma unroll
+  for (int r = 0; r < PER; r++) {
+    int mm = tid + r * nthreads;
+    if (mm < 1) mm = 1;
+    if (mm > (1 << LB) - 1) mm = (1 << LB) - 1;
+    const int sl = 31 - __builtin_clz(mm);
+    v[r] = tw_load(tw + (((1 << S0) + b) << sl) + (mm - (1 << sl)));
+  }
+}
+template <int LB, class TW, int PER>
+__device__ __forceinline__ void block_twiddles_store(TW *ltw, int tid, int nthreads, const TW (&v)[PER]) {
+#pragma unroll
+  for (int r = 0; r < PER; r++) {
+    const int mm = tid + r * nthreads;
+    if (mm >= 1 && mm < (1 << LB)) ltw[mm] = v[r];
+  }
+}
+
 // Inverse (GS): stages S+R-1 .. S (reverse order).
 template <class A, int LB, int S, int R>
 __device__ __forceinline__ void inv_pass(typename A::E (&x)[16], const int (&hi)[16 >> R], const typename A::Table &t,
@@ -291,9 +337,10 @@ template <> struct Sched<14> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 =
 //                              bit-reversed order) held in register slot r (r is a compile-time
 //                              constant after unrolling, so callers may index register arrays with it)
 // The final register layout is PassIdx<LB, LB-2, 2>: slot r = 4g+k holds element 4*(tid + T*g) + k.
-template <int LB, class A, class Load, class Store>
+template <int LB, class A, class Load, class Store, bool LTW = false>
 __device__ __forceinline__ void ntt_fwd_block_a(typename A::E *lds, Load load, Store store, const typename A::Table &t,
-                                                const Mod &m, int S0, int b, int tid_in = -1) {
+                                                const Mod &m, int S0, int b, int tid_in = -1,
+                                                const typename A::TW *ltw = nullptr /* LTW: block twiddle table in LDS */) {
   using SC = Sched<LB>;
   // a 1024-point block is one wavefront: callers may run several of them side by side in one workgroup (tid_in =
   // the lane id), so nothing in it may be a workgroup barrier
@@ -320,7 +367,8 @@ __device__ __forceinline__ void ntt_fwd_block_a(typename A::E *lds, Load load, S
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
     A::template fwd_begin<1>(x, kk);
-    fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
+    if constexpr (LTW && !P::UNIFORM) fwd_pass_lds<A, LB, S, R>(x, hi, ltw, kk);
+    else fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     if constexpr (SC::R3 == 0 && SC::R2 == 0) {
 #pragma unroll
       for (int g = 0; g < P::NG; g++)
@@ -339,7 +387,8 @@ __device__ __forceinline__ void ntt_fwd_block_a(typename A::E *lds, Load load, S
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
     A::template fwd_begin<2>(x, kk);
-    fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
+    if constexpr (LTW && !P::UNIFORM) fwd_pass_lds<A, LB, S, R>(x, hi, ltw, kk);
+    else fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     if constexpr (SC::R3 == 0) {
 #pragma unroll
       for (int g = 0; g < P::NG; g++)
@@ -358,7 +407,8 @@ __device__ __forceinline__ void ntt_fwd_block_a(typename A::E *lds, Load load, S
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
     A::template fwd_begin<3>(x, kk);
-    fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
+    if constexpr (LTW && !P::UNIFORM) fwd_pass_lds<A, LB, S, R>(x, hi, ltw, kk);
+    else fwd_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
 #pragma unroll
     for (int g = 0; g < P::NG; g++)
 #pragma unroll
