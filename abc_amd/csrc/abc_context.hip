@@ -30,6 +30,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_split2 = env_on("ABC_HIP_NO_SPLIT2");
   s.no_split3 = env_on("ABC_HIP_NO_SPLIT3");
   s.no_split4 = env_on("ABC_HIP_NO_SPLIT4");
+  s.split4_special = env_on("ABC_HIP_SPLIT4_SPECIAL");
   s.no_tensor_decomp = env_on("ABC_HIP_NO_TENSOR_DECOMP");
   s.no_tensor_intt = env_on("ABC_HIP_NO_TENSOR_INTT");
   s.tailmac_serial = env_on("ABC_HIP_TAILMAC_SERIAL");
@@ -331,6 +332,8 @@ static int build_context(abc_hip_ctx *c) {
   DevCtx &dc = c->dc;
   dc.mods = c->d_mods; dc.tw = c->d_tw; dc.ftw = c->d_ftw; dc.cst = c->d_cst; dc.slot_map = c->d_slot_map;
   dc.logn = logn; dc.n = (int)N; dc.K = K; dc.L = L;
+  dc.ps = (int)N;
+  if (const char *e = std::getenv("ABC_HIP_SCRATCH_PAD")) dc.ps = (int)N + (std::atoi(e) / 2) * 2;  // words, kept even (16-byte rows)
   dc.id_bsk = id_bsk; dc.id_t = id_t; dc.id_gamma = id_gamma; dc.id_mtilde = -1;
   return 0;
 }

@@ -68,6 +68,7 @@ struct DevCtx {
   const DevConst *cst;  //
   const u32 *slot_map;  // [N] BatchEncoder index map (BFV)
   int logn, n;
+  int ps;               // scratch limb stride of the split kernels in words: n + pad (HBM channel spread)
   int K, L;             // key-level primes, data limbs
   int id_bsk, id_t, id_gamma, id_mtilde;  // modulus ids: key primes are 0..K-1
 };
@@ -130,7 +131,7 @@ struct abc_hip_ctx {
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
   struct Switches {
-    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_tensor_decomp = false, no_tensor_intt = false;
+    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
     bool tailmac_serial = false, no_galois_fusion = false;
     size_t chunk = 0, few_limbs = 48;
     int lanes = 2;

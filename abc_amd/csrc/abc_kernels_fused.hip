@@ -573,7 +573,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_pass0_fp(DevCtx
 template <int LB, bool CKKS, bool GAL>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCtx c, const u64 *__restrict__ src, size_t src_stride,
                                                                            double *__restrict__ part, int nl, int per_target,
-                                                                           u32 gelt) {
+                                                                           u32 gelt, int padded) {
   static_assert(LB == 14, "split transforms are laid out for N = 2^14");
   __shared__ double lds[CKKS ? lds_words(LB) : 1];
   const size_t N = (size_t)1 << LB;
@@ -612,7 +612,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCt
 #pragma unroll
     for (int k = 0; k < 16; k++) y[k] = x[k];
     fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
-    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * N;
+    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * (padded ? (size_t)c.ps : N);
 #pragma unroll
     for (int k = 0; k < 16; k++) dst[(k << 10) + tid] = y[k];
   }
@@ -799,7 +799,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_split2_tensor_pass0_fp(DevCt
 #pragma unroll
     for (int k = 0; k < 16; k++) y[k] = src[k];
     fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
-    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * N;
+    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * (size_t)c.ps;
 #pragma unroll
     for (int k = 0; k < 16; k++) dst[(k << 10) + tid] = y[k];
   }
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split2_tailmac_fp(DevCtx
   const bool diag = (I < nl);  // limb I of the operand is already in NTT form modulo q_I: no transform for J = I
   if (!(diag && J == I)) {
     double *buf = dyn + J * lds_words(10);
-    const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + base;
+    const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * (size_t)c.ps + base;
     ntt_fwd_block_a<10, FpArith>(
         buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk,
         lane);
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split2_tailmac_fp(DevCtx
     // stages 13..4 of the special-prime limb's inverse transform on this block, one wavefront per component
     for (int comp = J; comp < 2; comp += nl) {
       double *buf = dyn + comp * lds_words(10);
-      double *__restrict__ dst = tsp_half + (ct * 2 + comp) * N + base;
+      double *__restrict__ dst = tsp_half + (ct * 2 + comp) * (size_t)c.ps + base;
       ntt_inv_block_a<10, FpArith>(
           buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, 4, blk, lane);
     }
@@ -946,7 +946,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_split2_moddown_fp(DevCtx c, 
     const Mod ms = mod_at(c, c.K - 1);
     const FpTable ts = fp_table(c, c.K - 1);
     const FpK ks = FpArith::consts(ms);
-    const double *__restrict__ src = tsp_half + cc * N;
+    const double *__restrict__ src = tsp_half + cc * (size_t)c.ps;
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = src[(k << 10) + tid];
     FpArith::centre16(x, ks);
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_split3_pass_fp(DevCtx c, const double *
     const Mod ms = mod_at(c, c.K - 1);
     const FpTable ts = fp_table(c, c.K - 1);
     const FpK ks = FpArith::consts(ms);
-    const double *__restrict__ src = tsp_half + cc * N;
+    const double *__restrict__ src = tsp_half + cc * (size_t)c.ps;
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = src[(k << 10) + p];
     FpArith::centre16(x, ks);
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_split3_pass_fp(DevCtx c, const double *
 #pragma unroll
     for (int k = 0; k < 16; k++) y[k] = x[k] + fix;
     fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
-    double *__restrict__ dst = tpart + (cc * nl + j) * N;
+    double *__restrict__ dst = tpart + (cc * nl + j) * (size_t)c.ps;
 #pragma unroll
     for (int k = 0; k < 16; k++) dst[(k << 10) + p] = y[k];
   }
@@ -1088,9 +1088,9 @@ __global__ __launch_bounds__(NL ? (NL + 1) * 64 : 832) void k_split3_main_fp(Dev
     const double *__restrict__ src;
     if (W < nl - 1) {
       const int J = W < I ? W : W + 1;
-      src = part + ((ct * (nl + 1) + I) * nl + J) * N + base;
+      src = part + ((ct * (nl + 1) + I) * nl + J) * (size_t)c.ps + base;
     } else {
-      src = tpart + ((ct * 2 + (W - (nl - 1))) * nl + I) * N + base;
+      src = tpart + ((ct * 2 + (W - (nl - 1))) * nl + I) * (size_t)c.ps + base;
     }
     ntt_fwd_block_a<10, FpArith>(
         buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk,
@@ -1228,8 +1228,8 @@ __global__ __launch_bounds__(512, 2) void k_split4_main_fp(DevCtx c, const doubl
   block_twiddles_fetch<10, f64x2, PER>(t.tw, 4, blk, (int)threadIdx.x, NT, twv);
   const bool has_limb = W <= nl;  // wavefront-uniform
   const int Wc = has_limb ? W : 0;
-  const double *__restrict__ src = (Wc < nl - 1) ? part + ((ct * (nl + 1) + I) * nl + (Wc < I ? Wc : Wc + 1)) * N + base
-                                                 : tpart + ((ct * 2 + (Wc - (nl - 1))) * nl + I) * N + base;
+  const double *__restrict__ src = (Wc < nl - 1) ? part + ((ct * (nl + 1) + I) * nl + (Wc < I ? Wc : Wc + 1)) * (size_t)c.ps + base
+                                                 : tpart + ((ct * 2 + (Wc - (nl - 1))) * nl + I) * (size_t)c.ps + base;
   double xin[16];
   if (has_limb) {
 #pragma unroll
@@ -1345,12 +1345,99 @@ static bool launch_split4_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   return true;
 }
 
+
+// split4 twin of the special-prime workgroups of k_split2_tailmac_fp: LDS twiddle tables (forward and inverse), key slices
+// requested before the transforms, 512 threads (one coefficient pair each)
+template <int NL>
+__global__ __launch_bounds__(512, 2) void k_split4_special_fp(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
+                                                              double *__restrict__ tsp_half) {
+  extern __shared__ double dyn[];  // max(nl, 2) transform buffers, forward table, inverse table
+  static_assert(NL <= 8, "one wavefront per limb, eight wavefronts");
+  constexpr int nl = NL, NB = NL < 2 ? 2 : NL, NT = 512, PER = 2;
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & 15;
+  const size_t ct = (size_t)(blockIdx.x >> 4);
+  const size_t N = (size_t)c.n, base = (size_t)blk << 10;
+  const int ki = c.K - 1;
+  const Mod m = mod_at(c, ki);
+  const FpTable t = fp_table(c, ki);
+  const double q = m.qd, qinv = m.qinv;
+  f64x2 *ltw = reinterpret_cast<f64x2 *>(dyn + NB * lds_words(10)), *litw = ltw + 1024;
+  f64x2 twv[PER], itwv[PER];
+  block_twiddles_fetch<10, f64x2, PER>(t.tw, 4, blk, (int)threadIdx.x, NT, twv);
+  const bool has_limb = W < nl;
+  const double *__restrict__ src = part + ((ct * (nl + 1) + nl) * nl + (has_limb ? W : 0)) * (size_t)c.ps + base;
+  double xin[16];
+  if (has_limb) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) xin[k] = src[(k << 6) + lane];
+  }
+  block_twiddles_fetch<10, f64x2, PER>(t.itw, 4, blk, (int)threadIdx.x, NT, itwv);
+  const int e = 2 * (int)threadIdx.x;
+  u64x2 k0[NL], k1[NL];
+#pragma unroll
+  for (int Jx = 0; Jx < NL; Jx++) {
+    k0[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
+    k1[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
+  }
+  block_twiddles_store<10, f64x2, PER>(ltw, (int)threadIdx.x, NT, twv);
+  block_twiddles_store<10, f64x2, PER>(litw, (int)threadIdx.x, NT, itwv);
+  __syncthreads();
+  if (has_limb) {
+    double *buf = dyn + W * lds_words(10);
+    auto ld = [&](int r, int) { return fp_centre(xin[r], q, qinv); };
+    auto st = [&](int, int i, double v) { buf[lds_pad(i)] = v; };
+    ntt_fwd_block_a<10, FpArith, decltype(ld), decltype(st), true>(buf, ld, st, t, m, 4, blk, lane, ltw);
+  }
+  __syncthreads();
+  double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
+#pragma unroll
+  for (int Jx = 0; Jx < NL; Jx++) {
+    const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
+    s0[0] += fp_mulmod(v.x, fp_from_u64(k0[Jx].x), q, qinv);
+    s0[1] += fp_mulmod(v.y, fp_from_u64(k0[Jx].y), q, qinv);
+    s1[0] += fp_mulmod(v.x, fp_from_u64(k1[Jx].x), q, qinv);
+    s1[1] += fp_mulmod(v.y, fp_from_u64(k1[Jx].y), q, qinv);
+  }
+  // park the two sums (centred) in buffers 0 and 1: a thread overwrites only the words it alone has read
+  f64x2 r;
+  r.x = fp_centre(s0[0], q, qinv); r.y = fp_centre(s0[1], q, qinv);
+  *reinterpret_cast<f64x2 *>(dyn + lds_pad(e)) = r;
+  r.x = fp_centre(s1[0], q, qinv); r.y = fp_centre(s1[1], q, qinv);
+  *reinterpret_cast<f64x2 *>(dyn + lds_words(10) + lds_pad(e)) = r;
+  __syncthreads();
+  if (W < 2) {  // stages 13..4 of the special-prime limb's inverse transform on this block, one wavefront per component
+    double *buf = dyn + W * lds_words(10);
+    double *__restrict__ dst = tsp_half + (ct * 2 + W) * (size_t)c.ps + base;
+    auto ld = [&](int, int i) { return buf[lds_pad(i)]; };
+    auto st = [&](int, int i, double v) { dst[i] = v; };
+    ntt_inv_block_a<10, FpArith, decltype(ld), decltype(st), true>(buf, ld, st, t, m, 4, blk, lane, litw);
+  }
+}
+
+static bool launch_split4_special(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const u64 *key, double *tsp_half) {
+  if (nl < 1 || nl > 4) return false;
+  const dim3 grid((unsigned)(cc * 16)), block(512);
+  const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8 + 2 * 1024 * 16;
+  switch (nl) {
+    case 1: hipLaunchKernelGGL(k_split4_special_fp<1>, grid, block, lds, st, c->dc, part, key, tsp_half); break;
+    case 2: hipLaunchKernelGGL(k_split4_special_fp<2>, grid, block, lds, st, c->dc, part, key, tsp_half); break;
+    case 3: hipLaunchKernelGGL(k_split4_special_fp<3>, grid, block, lds, st, c->dc, part, key, tsp_half); break;
+    default: hipLaunchKernelGGL(k_split4_special_fp<4>, grid, block, lds, st, c->dc, part, key, tsp_half); break;
+  }
+  return true;
+}
+
 // K2a..K2c on one chunk (the half-done decomposition limbs are in s.dec)
 template <int MODE, bool GAL>
 static void launch_split3(hipStream_t st, abc_hip_ctx *c, const FusedScratch &s, size_t cc, int nl, const u64 *opa, const u64 *opb,
                           size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt) {
-  launch_split2_tailmac<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, opa, opb, opa_stride, opb_stride, add_c1, key, s.ksacc,
-                                   (double *)s.tsp, gelt, 1);
+  // (k_split4_special_fp, the LDS-table twin of the special-prime workgroups, measured 9 % slower than this: two tables to
+  // fill for four transforms; kept behind ABC_HIP_SPLIT4_SPECIAL=1 for A/B)
+  if (!c->sw.split4_special || !launch_split4_special(st, c, cc, nl, (const double *)s.dec, key, (double *)s.tsp))
+    launch_split2_tailmac<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, opa, opb, opa_stride, opb_stride, add_c1, key, s.ksacc,
+                                     (double *)s.tsp, gelt, 1);
   hipLaunchKernelGGL(k_split3_pass_fp<14>, dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, (const double *)s.tsp, (double *)s.ksacc,
                      nl);
   if (!c->sw.no_split4 && launch_split4_main<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, (const double *)s.ksacc, opa, opb,
@@ -1508,7 +1595,10 @@ template <int LB>
 static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count) {
   const size_t N = (size_t)1 << LB;
   const ChunkPlan p = plan_chunks(c, nl, count);
-  const size_t per_ct = fused_scratch_limbs(nl) * N;
+  // scratch limbs of the split2+ kernels are c->dc.ps words apart (N plus an optional pad, see abc_hip_ctx_create)
+  const bool use2 = LB == 14 && all_fp(c) && !c->sw.no_tensor_decomp && !c->sw.no_split && !c->sw.no_split2 && nl <= 12;
+  const size_t SN = use2 ? (size_t)c->dc.ps : N;
+  const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
   LaneScope scope(c, p.lanes);
   if (scope.fork()) return 1;
@@ -1518,7 +1608,7 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
     const size_t cc = (count - off < p.chunk) ? count - off : p.chunk;
     const int l = (p.lanes > 1) ? turn % p.lanes : 0;
     hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
-    const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, N);
+    const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, SN);
     const bool fuse_decomp = all_fp(c) && !c->sw.no_tensor_decomp;
     bool split = false;
     if constexpr (LB == 14) split = fuse_decomp && !c->sw.no_split;
@@ -1582,7 +1672,9 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
   const size_t N = (size_t)1 << LB;
   const bool ckks = (c->scheme == 2);
   const ChunkPlan p = plan_chunks(c, nl, count);
-  const size_t per_ct = fused_scratch_limbs(nl) * N;
+  const bool use2 = LB == 14 && ckks && all_fp(c) && !c->sw.no_split && !c->sw.no_split2 && nl <= 12;
+  const size_t SN = use2 ? (size_t)c->dc.ps : N;
+  const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
   LaneScope scope(c, p.lanes);
   if (scope.fork()) return 1;
@@ -1591,7 +1683,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     const size_t cc = (count - off < p.chunk) ? count - off : p.chunk;
     const int l = (p.lanes > 1) ? turn % p.lanes : 0;
     hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
-    const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, N);
+    const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, SN);
     const u64 *tg = target + off * target_stride;
     const u64 *coef = tg;
     size_t coef_stride = target_stride;
@@ -1601,13 +1693,13 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
       if (split && ckks)
         hipLaunchKernelGGL((gelt ? k_fused_operand_pass0_fp<LB, true, true> : k_fused_operand_pass0_fp<LB, true, false>),
                            dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, 0,
-                           gelt);
+                           gelt, use2 ? 1 : 0);
       else if (split && cc * nl < 128)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl * (nl + 1))), dim3((1 << LB) / 16), 0, st,
-                           c->dc, tg, target_stride, (double *)s.dec, nl, 1, 0u);
+                           c->dc, tg, target_stride, (double *)s.dec, nl, 1, 0u, 0);
       else if (split)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
-                           target_stride, (double *)s.dec, nl, 0, 0u);
+                           target_stride, (double *)s.dec, nl, 0, 0u, 0);
     }
     if constexpr (LB == 14) {
       if (split && ckks && !c->sw.no_split2 && nl <= 12) {

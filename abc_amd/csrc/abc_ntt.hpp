@@ -259,6 +259,26 @@ __device__ __forceinline__ void inv_pass(typename A::E (&x)[16], const int (&hi)
   }
 }
 
+template <class A, int LB, int S, int R>
+__device__ __forceinline__ void inv_pass_lds(typename A::E (&x)[16], const int (&hi)[16 >> R], const typename A::TW *ltw,
+                                             const typename A::K &kk) {
+  constexpr int NG = 16 >> R;
+#pragma unroll
+  for (int u = R - 1; u >= 0; u--) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      int base = (1 << (S + u)) + (hi[g] << u);
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) {
+        if (k & half) continue;
+        int idx = base + (k >> (R - u));
+        A::inv(x[g * (1 << R) + k], x[g * (1 << R) + (k | half)], ltw[idx], kk);
+      }
+    }
+  }
+}
+
 // Index bookkeeping of one pass: group p has lo = p mod G, hi = p / G (G = 2^(LB-S-R)); its k-th element sits at
 // (hi << (LB-S)) + (k << logG) + lo.  Group ownership is wave-contiguous: lane l of wave w owns groups
 // w*64*NG + g*64 + l.  For the first pass (NG = 1) that is simply p = tid; for every later pass (S >= LB-10) a
@@ -427,9 +447,10 @@ __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, 
 //                              as the forward transform's final one
 // store(r, i, v)               v in [0,2q): coefficient i BEFORE the N^-1 scaling (caller scales:
 //                              for a sub-block the scaling belongs to the final strided pass)
-template <int LB, class A, class Load, class Store>
+template <int LB, class A, class Load, class Store, bool LTW = false>
 __device__ __forceinline__ void ntt_inv_block_a(typename A::E *lds, Load load, Store store, const typename A::Table &t,
-                                                const Mod &m, int S0, int b, int tid_in = -1) {
+                                                const Mod &m, int S0, int b, int tid_in = -1,
+                                                const typename A::TW *ltw = nullptr /* LTW: block table of INVERSE twiddles in LDS */) {
   using SC = Sched<LB>;
   // as in the forward transform: a 1024-point block is one wavefront (tid_in = the lane id), nothing in it may then be a
   // workgroup barrier
@@ -447,7 +468,8 @@ __device__ __forceinline__ void ntt_inv_block_a(typename A::E *lds, Load load, S
 #pragma unroll
       for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
     A::template inv_begin<0>(x, kk);
-    inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
+    if constexpr (LTW && !P::UNIFORM) inv_pass_lds<A, LB, S, R>(x, hi, ltw, kk);
+    else inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
     wave_sync();  // all passes but the last are local to a wave
   }
@@ -465,7 +487,8 @@ __device__ __forceinline__ void ntt_inv_block_a(typename A::E *lds, Load load, S
         for (int k = 0; k < (1 << R); k++) x[g * (1 << R) + k] = load(g * (1 << R) + k, P::elem(hi[g], lo[g], k));
     }
     A::template inv_begin<(SC::R3 != 0 ? 1 : 0)>(x, kk);
-    inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
+    if constexpr (LTW && !P::UNIFORM) inv_pass_lds<A, LB, S, R>(x, hi, ltw, kk);
+    else inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
     wave_sync();
   }
@@ -476,7 +499,8 @@ __device__ __forceinline__ void ntt_inv_block_a(typename A::E *lds, Load load, S
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
     A::template inv_begin<(SC::R3 != 0 ? 2 : 1)>(x, kk);
-    inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
+    if constexpr (LTW && !P::UNIFORM) inv_pass_lds<A, LB, S, R>(x, hi, ltw, kk);
+    else inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
     lds_store<LB, S, R>(lds, x, hi, lo);
     if constexpr (LB <= 10) wave_sync(); else block_sync_lds();
   }
@@ -487,7 +511,8 @@ __device__ __forceinline__ void ntt_inv_block_a(typename A::E *lds, Load load, S
     P::groups(tid, hi, lo);
     lds_load<LB, S, R>(lds, x, hi, lo);
     A::template inv_begin<(SC::R3 != 0 ? 3 : 2)>(x, kk);
-    inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
+    if constexpr (LTW && !P::UNIFORM) inv_pass_lds<A, LB, S, R>(x, hi, ltw, kk);
+    else inv_pass<A, LB, S, R>(x, hi, t, kk, S0, b);
 #pragma unroll
     for (int g = 0; g < P::NG; g++)
 #pragma unroll

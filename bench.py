@@ -282,7 +282,8 @@ def run_rank(args):
                        "sharding": "independent ciphertext pairs per rank, result gather only"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
-                         "kernel": "abc_hip_mul_relin (rank 0's launch): see DESIGN.md section 4 for its kernels",
+                         "kernel": "abc_hip_mul_relin (rank 0's launch) = k_split2_tensor_pass0_fp + k_split2_tailmac_fp (special prime) + "
+                                   "k_split3_pass_fp + k_split4_main_fp (dominant), DESIGN.md section 4",
                          "algorithmic_bytes_per_launch": ALGO_BYTES * B, "launch_ms": launch_ms},
         }
         if gather_ms is not None:

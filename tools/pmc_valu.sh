@@ -16,7 +16,7 @@ for sub in ("insts", "busy"):
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].replace("void ", "").split("(")[0]
-            if "abc::k_fused" not in name and "abc::k_split2" not in name:
+            if "abc::k_fused" not in name and "abc::k_split" not in name:
                 continue
             d = res.setdefault(name, {})
             d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
