@@ -49,7 +49,7 @@ def main():
         rd = fs * factor / 1024.0
         wr = ws / 1024.0
         kernels[short(name)] = {"launches": n, "read_MiB_corrected_total": rd, "write_MiB_total": wr}
-        if "fused" in name or "split2" in name:
+        if "fused" in name or "split" in name:
             tot_r += rd
             tot_w += wr
     # launches of the hot call in the profiled run: warmup 1 + steps 2 + parity/extra calls are all the same batch size
