@@ -23,7 +23,7 @@ SYMBOLS = [
     "abc_hip_default_bfv_primes", "abc_hip_plain_modulus_batching", "abc_hip_create_primes", "abc_hip_ctx_info",
     "abc_hip_set_stream", "abc_hip_sync", "abc_hip_ctx_reload_env", "abc_hip_malloc", "abc_hip_free", "abc_hip_trim",
     "abc_hip_cached_bytes", "abc_hip_memcpy_h2d", "abc_hip_memcpy_d2h",
-    "abc_hip_memcpy_d2d", "abc_hip_keygen", "abc_hip_load_secret_key", "abc_hip_load_public_key",
+    "abc_hip_memcpy_d2d", "abc_hip_keygen", "abc_hip_keygen_secure", "abc_hip_encrypt_secure", "abc_hip_load_secret_key", "abc_hip_load_public_key",
     "abc_hip_load_relin_key", "abc_hip_load_galois_key", "abc_hip_get_secret_key", "abc_hip_get_public_key",
     "abc_hip_get_relin_key", "abc_hip_get_galois_key", "abc_hip_num_galois_keys", "abc_hip_galois_elt_at",
     "abc_hip_galois_elt_from_step", "abc_hip_batch_encode", "abc_hip_batch_decode", "abc_hip_encrypt", "abc_hip_decrypt",
@@ -172,8 +172,12 @@ class Context:
         _chk(lib().abc_hip_set_stream(self.h, C.c_void_p(stream_ptr)))
 
     # ---- keys ----
-    def keygen(self, seed):
-        _chk(lib().abc_hip_keygen(self.h, C.c_uint64(seed)))
+    def keygen(self, seed=None):
+        """seed=None: OS-keyed ChaCha20 (deployment); an integer: the reproducible test sampling spec shared with the oracle"""
+        if seed is None:
+            _chk(lib().abc_hip_keygen_secure(self.h))
+        else:
+            _chk(lib().abc_hip_keygen(self.h, C.c_uint64(seed)))
 
     def load_keys(self, sk=None, pk=None, relin=None, galois=None):
         def p(a):
@@ -352,13 +356,16 @@ class Context:
         pb.free(); out.free()
         return r if np.ndim(plain) == 2 else r[0]
 
-    def encrypt(self, plain, seed):
+    def encrypt(self, plain, seed=None):
         per = (self.n,) if self.scheme == BFV else (self.L, self.n)
         p = np.ascontiguousarray(plain, dtype=np.uint64).reshape((-1,) + per)
         pb = self.upload(p)
         shp = (p.shape[0], 2, self.L, self.n)
         out = self.alloc(int(np.prod(shp)) * 8)
-        self.op("encrypt", pb.ptr, C.c_uint64(seed), out.ptr, C.c_size_t(p.shape[0]))
+        if seed is None:
+            self.op("encrypt_secure", pb.ptr, out.ptr, C.c_size_t(p.shape[0]))
+        else:
+            self.op("encrypt", pb.ptr, C.c_uint64(seed), out.ptr, C.c_size_t(p.shape[0]))
         r = self.download(out, shp)
         pb.free(); out.free()
         return r if np.ndim(plain) == len(per) + 1 else r[0]

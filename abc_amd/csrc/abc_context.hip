@@ -734,6 +734,15 @@ int abc_hip_keygen(abc_hip_ctx *c, uint64_t seed) {
     return 1;
   }
 }
+int abc_hip_keygen_secure(abc_hip_ctx *c) {
+  CTX_GUARD(c);
+  try {
+    return keygen_secure(c);
+  } catch (const std::exception &e) {
+    set_error(e.what());
+    return 1;
+  }
+}
 static int load_key(abc_hip_ctx *c, uint64_t **slot, const uint64_t *h, size_t words) {
   if (!*slot) ABC_HIP_CHECK(hipMalloc(slot, words * 8));
   ABC_HIP_CHECK(hipMemcpy(*slot, h, words * 8, hipMemcpyHostToDevice));
@@ -777,6 +786,7 @@ uint32_t abc_hip_galois_elt_from_step(abc_hip_ctx *c, int step) { return c ? elt
 int abc_hip_batch_encode(abc_hip_ctx *c, const int64_t *v, uint64_t *p, size_t count) { CTX_GUARD(c); return batch_encode(c, v, p, count); }
 int abc_hip_batch_decode(abc_hip_ctx *c, const uint64_t *p, int64_t *v, size_t count) { CTX_GUARD(c); return batch_decode(c, p, v, count); }
 int abc_hip_encrypt(abc_hip_ctx *c, const uint64_t *p, uint64_t seed, uint64_t *ct, size_t count) { CTX_GUARD(c); return encrypt(c, p, seed, ct, count); }
+int abc_hip_encrypt_secure(abc_hip_ctx *c, const uint64_t *p, uint64_t *ct, size_t count) { CTX_GUARD(c); return encrypt_secure(c, p, ct, count); }
 int abc_hip_decrypt(abc_hip_ctx *c, const uint64_t *ct, int size, int nl, uint64_t *p, size_t count) {
   CTX_GUARD(c);
   if (nl < 1 || nl > c->L) { set_error("decrypt: bad limb count"); return 1; }

@@ -201,6 +201,8 @@ int batch_decode(abc_hip_ctx *c, const u64 *plain, int64_t *values, size_t count
 int encrypt(abc_hip_ctx *c, const u64 *plain, uint64_t seed, u64 *ct, size_t count);
 int decrypt(abc_hip_ctx *c, const u64 *ct, int size, int nl, u64 *plain, size_t count);
 int keygen(abc_hip_ctx *c, uint64_t seed);
+int keygen_secure(abc_hip_ctx *c);
+int encrypt_secure(abc_hip_ctx *c, const u64 *plain, u64 *ct, size_t count);
 int microbench(abc_hip_ctx *c, int which, int iters, double *ms);
 
 // LDS-resident fast paths (N <= 2^14); return -1 if not applicable (caller falls back to the generic kernels)

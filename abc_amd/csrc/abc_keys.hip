@@ -11,6 +11,7 @@
 // small polynomials travel to the device; all ring arithmetic (NTTs, products, modulus switching)
 // runs in HIP kernels.
 #include <cstring>
+#include <sys/random.h>
 
 #include "abc_context.hpp"
 #include "abc_host_math.hpp"
@@ -25,26 +26,16 @@ static inline unsigned grid_for(size_t items, int block) {
   return (unsigned)(g < cap ? (g ? g : 1) : cap);
 }
 
-// ---------------- host sampler ----------------
-struct Rng {
-  uint64_t s[4];
-  explicit Rng(uint64_t seed) {
-    uint64_t x = seed;
-    for (auto &w : s) {
-      uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-      w = z ^ (z >> 31);
-    }
-  }
-  static uint64_t rotl(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
-  uint64_t next() {
-    const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = rotl(s[3], 45);
-    return r;
-  }
+// ---------------- host samplers ----------------
+// Two generators behind one interface.  Rng (splitmix64-seeded xoshiro256**) is this repo's SAMPLING SPEC for parity tests:
+// the oracle implements the same stream, so keys and ciphertexts are bit-comparable -- it is NOT a cryptographic generator
+// (64-bit seed, linear state) and is only reached through the explicitly seeded entry points.  ChaCha (ChaCha20 keyed with
+// 256 bits from getrandom(2)) serves abc_hip_keygen_secure / abc_hip_encrypt_secure, which is what the plugin classes use
+// when no test seed is given: secret material (secret key, errors, encryption randomness) and public material (the uniform
+// `a` polynomials that are published inside the keys) come from independently keyed streams.
+struct Sampler {
+  virtual uint64_t next() = 0;
+  virtual ~Sampler() {}
   int8_t ternary() {
     for (;;) {
       const uint64_t x = next();
@@ -60,6 +51,76 @@ struct Rng {
     uint64_t x;
     do x = next(); while (x >= lim);
     return x % q;
+  }
+};
+struct Rng final : Sampler {
+  uint64_t s[4];
+  explicit Rng(uint64_t seed) {
+    uint64_t x = seed;
+    for (auto &w : s) {
+      uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      w = z ^ (z >> 31);
+    }
+  }
+  static uint64_t rotl(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
+  uint64_t next() override {
+    const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return r;
+  }
+};
+// ChaCha20 (RFC 8439 block function) as a deterministic random bit generator: 256-bit key from the operating system,
+// 64-bit block counter, 64-bit stream id
+struct ChaCha final : Sampler {
+  uint32_t key[8], buf[16];
+  uint64_t counter = 0, stream;
+  int pos = 16;
+  bool ok = false;
+  explicit ChaCha(uint64_t stream_id) : stream(stream_id) {
+    size_t got = 0;
+    unsigned char *k = reinterpret_cast<unsigned char *>(key);
+    while (got < sizeof(key)) {
+      const ssize_t r = getrandom(k + got, sizeof(key) - got, 0);
+      if (r <= 0) return;
+      got += (size_t)r;
+    }
+    ok = true;
+  }
+  ~ChaCha() override {
+    explicit_bzero(key, sizeof(key));
+    explicit_bzero(buf, sizeof(buf));
+  }
+  static uint32_t rotl32(uint32_t v, int k) { return (v << k) | (v >> (32 - k)); }
+  static void qr(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d) {
+    a += b; d ^= a; d = rotl32(d, 16);
+    c += d; b ^= c; b = rotl32(b, 12);
+    a += b; d ^= a; d = rotl32(d, 8);
+    c += d; b ^= c; b = rotl32(b, 7);
+  }
+  void refill() {
+    uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 8; i++) st[4 + i] = key[i];
+    st[12] = (uint32_t)counter; st[13] = (uint32_t)(counter >> 32);
+    st[14] = (uint32_t)stream; st[15] = (uint32_t)(stream >> 32);
+    uint32_t x[16];
+    for (int i = 0; i < 16; i++) x[i] = st[i];
+    for (int r = 0; r < 10; r++) {
+      qr(x[0], x[4], x[8], x[12]); qr(x[1], x[5], x[9], x[13]); qr(x[2], x[6], x[10], x[14]); qr(x[3], x[7], x[11], x[15]);
+      qr(x[0], x[5], x[10], x[15]); qr(x[1], x[6], x[11], x[12]); qr(x[2], x[7], x[8], x[13]); qr(x[3], x[4], x[9], x[14]);
+    }
+    for (int i = 0; i < 16; i++) buf[i] = x[i] + st[i];
+    counter++;
+    pos = 0;
+  }
+  uint64_t next() override {
+    if (pos >= 16) refill();
+    const uint64_t v = (uint64_t)buf[pos] | ((uint64_t)buf[pos + 1] << 32);
+    pos += 2;
+    return v;
   }
 };
 
@@ -147,14 +208,15 @@ __global__ __launch_bounds__(256) void k_enc_mul_pk(DevCtx c, const u64 *u, cons
 }
 
 // ---------------- key generation ----------------
-static int make_kskey(abc_hip_ctx *c, Rng &rng, const u64 *d_new_key, u64 *d_key, std::vector<uint64_t> &h_a,
+// pub draws the uniform `a` polynomials (published in the key), sec the errors; the seeded spec passes one generator as both
+static int make_kskey(abc_hip_ctx *c, Sampler &pub, Sampler &sec, const u64 *d_new_key, u64 *d_key, std::vector<uint64_t> &h_a,
                       std::vector<int8_t> &h_e, u64 *d_a, int8_t *d_e8, u64 *d_e, int nkeys) {
   const size_t N = (size_t)c->n;
   const int K = c->K;
   for (int i = 0; i < nkeys; i++) {
     for (int j = 0; j < K; j++)
-      for (size_t x = 0; x < N; x++) h_a[((size_t)i * K + j) * N + x] = rng.uniform(c->primes[j]);
-    for (size_t x = 0; x < N; x++) h_e[(size_t)i * N + x] = rng.cbd();
+      for (size_t x = 0; x < N; x++) h_a[((size_t)i * K + j) * N + x] = pub.uniform(c->primes[j]);
+    for (size_t x = 0; x < N; x++) h_e[(size_t)i * N + x] = sec.cbd();
   }
   ABC_HIP_CHECK(hipMemcpyAsync(d_a, h_a.data(), (size_t)nkeys * K * N * 8, hipMemcpyHostToDevice, c->stream));
   ABC_HIP_CHECK(hipMemcpyAsync(d_e8, h_e.data(), (size_t)nkeys * N, hipMemcpyHostToDevice, c->stream));
@@ -171,10 +233,19 @@ static int make_kskey(abc_hip_ctx *c, Rng &rng, const u64 *d_new_key, u64 *d_key
   return 0;
 }
 
+static int keygen_with(abc_hip_ctx *c, Sampler &pub, Sampler &sec);
 int keygen(abc_hip_ctx *c, uint64_t seed) {
+  Rng rng(seed);
+  return keygen_with(c, rng, rng);
+}
+int keygen_secure(abc_hip_ctx *c) {
+  ChaCha sec(1), pub(2);  // independently keyed: nothing derived from the secret stream is ever published
+  if (!sec.ok || !pub.ok) { set_error("keygen: getrandom failed"); return 1; }
+  return keygen_with(c, pub, sec);
+}
+static int keygen_with(abc_hip_ctx *c, Sampler &pub, Sampler &sec) {
   const size_t N = (size_t)c->n;
   const int K = c->K, L = c->L;
-  Rng rng(seed);
   LimbMap kmap{};
   for (int j = 0; j < K; j++) kmap.id[j] = j;
   // staging
@@ -187,7 +258,7 @@ int keygen(abc_hip_ctx *c, uint64_t seed) {
   ABC_HIP_CHECK(hipMalloc(&d_e8, (size_t)L * N));
   ABC_HIP_CHECK(hipMalloc(&d_newkey, (size_t)K * N * 8));
   // secret key
-  for (size_t x = 0; x < N; x++) h_e[x] = rng.ternary();
+  for (size_t x = 0; x < N; x++) h_e[x] = sec.ternary();
   ABC_HIP_CHECK(hipMemcpyAsync(d_e8, h_e.data(), N, hipMemcpyHostToDevice, c->stream));
   if (!c->d_sk) ABC_HIP_CHECK(hipMalloc(&c->d_sk, (size_t)K * N * 8));
   hipLaunchKernelGGL(k_small_to_rns, dim3(grid_for((size_t)K * N, 256)), dim3(256), 0, c->stream, c->dc, d_e8, (size_t)1, N, (size_t)0,
@@ -197,13 +268,13 @@ int keygen(abc_hip_ctx *c, uint64_t seed) {
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   // public key = one symmetric encryption of zero at key level
   if (!c->d_pk) ABC_HIP_CHECK(hipMalloc(&c->d_pk, (size_t)2 * K * N * 8));
-  if (make_kskey(c, rng, nullptr, c->d_pk, h_a, h_e, d_a, d_e8, d_e, 1)) return 1;
+  if (make_kskey(c, pub, sec, nullptr, c->d_pk, h_a, h_e, d_a, d_e8, d_e, 1)) return 1;
   // relinearisation key: switches s^2 -> s
   if (!c->d_relin) ABC_HIP_CHECK(hipMalloc(&c->d_relin, c->key_words() * 8));
   hipLaunchKernelGGL(k_dyadic_mul, dim3(grid_for((size_t)K * N, 256)), dim3(256), 0, c->stream, c->dc, c->d_sk, c->d_sk,
                      (size_t)0, d_newkey, kmap, K, (size_t)1);
   ABC_HIP_CHECK(hipGetLastError());
-  if (make_kskey(c, rng, d_newkey, c->d_relin, h_a, h_e, d_a, d_e8, d_e, L)) return 1;
+  if (make_kskey(c, pub, sec, d_newkey, c->d_relin, h_a, h_e, d_a, d_e8, d_e, L)) return 1;
   // Galois keys for the default element set (GaloisTool::get_elts_all): 2N-1, then 3^(2^i), 3^-(2^i)
   for (auto &kv : c->d_galois) (void)hipFree(kv.second);
   c->d_galois.clear();
@@ -221,16 +292,31 @@ int keygen(abc_hip_ctx *c, uint64_t seed) {
     u64 *d_key = nullptr;
     ABC_HIP_CHECK(hipMalloc(&d_key, c->key_words() * 8));
     if (launch_galois(c, c->d_sk, d_newkey, K, 1, elt, true)) return 1;
-    if (make_kskey(c, rng, d_newkey, d_key, h_a, h_e, d_a, d_e8, d_e, L)) return 1;
+    if (make_kskey(c, pub, sec, d_newkey, d_key, h_a, h_e, d_a, d_e8, d_e, L)) return 1;
     c->d_galois[elt] = d_key;
     c->galois_order.push_back(elt);
   }
+  // the staging buffers held the secret key, s^2 / g(s) and the errors: wipe before release
+  (void)hipMemsetAsync(d_e, 0, (size_t)L * K * N * 8, c->stream);
+  (void)hipMemsetAsync(d_e8, 0, (size_t)L * N, c->stream);
+  (void)hipMemsetAsync(d_newkey, 0, (size_t)K * N * 8, c->stream);
+  ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
+  explicit_bzero(h_e.data(), h_e.size());
   (void)hipFree(d_a); (void)hipFree(d_e); (void)hipFree(d_e8); (void)hipFree(d_newkey);
   return 0;
 }
 
 // ---------------- encryption ----------------
+static int encrypt_with(abc_hip_ctx *c, const u64 *plain, uint64_t seed, Sampler *secure, u64 *ct, size_t count);
 int encrypt(abc_hip_ctx *c, const u64 *plain, uint64_t seed, u64 *ct, size_t count) {
+  return encrypt_with(c, plain, seed, nullptr, ct, count);
+}
+int encrypt_secure(abc_hip_ctx *c, const u64 *plain, u64 *ct, size_t count) {
+  ChaCha sec(3);  // a fresh 256-bit key from the operating system per call: nothing is derived from the key seed
+  if (!sec.ok) { set_error("encrypt: getrandom failed"); return 1; }
+  return encrypt_with(c, plain, 0, &sec, ct, count);
+}
+static int encrypt_with(abc_hip_ctx *c, const u64 *plain, uint64_t seed, Sampler *secure, u64 *ct, size_t count) {
   if (!c->d_pk) { set_error("encrypt: no public key (call abc_hip_keygen or abc_hip_load_public_key)"); return 1; }
   if (!count) return 0;
   const size_t N = (size_t)c->n;
@@ -239,7 +325,8 @@ int encrypt(abc_hip_ctx *c, const u64 *plain, uint64_t seed, u64 *ct, size_t cou
   // host sampling: per ciphertext i the stream seed+i yields u, e0, e1
   std::vector<int8_t> h_small(count * 3 * N);
   for (size_t i = 0; i < count; i++) {
-    Rng rng(seed + i);
+    Rng seeded(seed + i);
+    Sampler &rng = secure ? *secure : static_cast<Sampler &>(seeded);
     int8_t *p = h_small.data() + i * 3 * N;
     for (size_t x = 0; x < N; x++) p[x] = rng.ternary();
     for (size_t x = 0; x < 2 * N; x++) p[N + x] = rng.cbd();
@@ -254,6 +341,7 @@ int encrypt(abc_hip_ctx *c, const u64 *plain, uint64_t seed, u64 *ct, size_t cou
   u64 *prodD = err + count * 2 * K * N, *prodS = prodD + count * 2 * L * N, *tmod = prodS + count * 2 * N;
   ABC_HIP_CHECK(hipMemcpyAsync(d_small, h_small.data(), count * 3 * N, hipMemcpyHostToDevice, c->stream));
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));  // h_small is a local
+  explicit_bzero(h_small.data(), h_small.size());
   LimbMap kmap{};
   for (int j = 0; j < K; j++) kmap.id[j] = j;
   // u (poly 0 of each [3][N] triple) -> residues at key level -> NTT
@@ -284,6 +372,8 @@ int encrypt(abc_hip_ctx *c, const u64 *plain, uint64_t seed, u64 *ct, size_t cou
   const LimbMap dmap = key_limb_map(c, L);
   if (ckks && launch_ntt_fwd(c, tmod, dmap, L, count * 2 * L)) return 1;
   if (launch_ks_finish(c, prodD, tmod, ct, nullptr, 0, false, L, count)) return 1;
+  // the encryption randomness (u, e0, e1 and everything derived before the modulus switch) lives in the workspace: wipe it
+  if (secure) ABC_HIP_CHECK(hipMemsetAsync(c->ws, 0, small_bytes + count * (size_t)(5 * K) * N * 8, c->stream));
   // add the message
   if (ckks) return ckks_add_plain(c, ct, plain, (size_t)L * N, ct, 2, L, count, 0);
   return bfv_addsub_plain(c, ct, plain, N, ct, 2, count, 0);

@@ -27,15 +27,26 @@ class HipCiphertext : public AbstractCiphertext {
     Buffer &operator=(const Buffer &) = delete;
   };
   std::shared_ptr<Buffer> buf;
+  // CKKS bookkeeping (BFV: nl = L, sc = 1): data limbs the value currently has and its scale.  seal::Ciphertext carries
+  // the same two (parms_id, scale); here the plugin classes also act on them, so the interpreter needs no CKKS knowledge:
+  // products are rescaled while a limb can be dropped, operands at different levels meet at the lower one.
+  int nl = 0;
+  double sc = 1.0;
 
-  static std::shared_ptr<Buffer> allocate(const HipCiphertextFactory &f);
+  static std::shared_ptr<Buffer> allocate(const HipCiphertextFactory &f, int level);
   std::unique_ptr<HipCiphertext> clone_impl() const;
-  std::unique_ptr<HipCiphertext> fresh() const;
+  std::unique_ptr<HipCiphertext> fresh(int level) const;
   uint64_t *in() const { return buf->p; }
   // destination of an in-place operation: the own buffer if nobody shares it, otherwise a fresh one, which `adopt`
   // installs after the operation has been issued
   std::shared_ptr<Buffer> target() const;
   void adopt(std::shared_ptr<Buffer> t) { buf = std::move(t); }
+  // CKKS helpers
+  void dropTo(int level);                       // mod_switch down (no-op at or below `level`)
+  void rescaleIfPossible();                     // divide by the last prime of the current level
+  static void checkScales(double a, double b);  // additions need (nearly) equal scales
+  // this and operand at a common level: returns the operand's pointer (possibly a temporary held in `keep`)
+  const uint64_t *alignWith(const HipCiphertext &operand, std::shared_ptr<Buffer> &keep);
 
  public:
   ~HipCiphertext() override;
@@ -46,6 +57,8 @@ class HipCiphertext : public AbstractCiphertext {
   HipCiphertext &operator=(HipCiphertext &&other);
 
   [[nodiscard]] const uint64_t *devicePtr() const { return buf->p; }
+  [[nodiscard]] int level() const { return nl; }
+  [[nodiscard]] double scale() const { return sc; }
   [[nodiscard]] uint64_t *devicePtr();  // for writing: un-shares first
   [[nodiscard]] const HipCiphertextFactory &getFactory() const override;
   [[nodiscard]] int noiseBits() const;  // SealCiphertext::noiseBits, SealCiphertext.cpp:80-83 (host-side diagnostic)

@@ -1,6 +1,6 @@
 #include "HipCiphertextFactory.hpp"
 
-#include <random>
+#include <cmath>
 #include <sstream>
 
 #include "../../include/abc_hip.h"
@@ -14,6 +14,21 @@ HipCiphertextFactory::HipCiphertextFactory(unsigned int numElementsPerCiphertext
   setupContext(device);
 }
 
+HipCiphertextFactory::HipCiphertextFactory(const HipSchemeConfig &cfg)
+    : ciphertextSlotSize(cfg.ringDegree), keySeed(cfg.seed), batch(cfg.batch), ckksMode(cfg.ckks), ckksScale(cfg.ckksScale),
+      ckksBits(cfg.ckksBits) {
+  if (!batch) throw std::runtime_error("HipCiphertextFactory: batch size must be at least 1");
+  if (ckksMode && ckksBits.size() < 2) throw std::runtime_error("HipCiphertextFactory: a CKKS chain needs a data limb and the special prime");
+  setupContext(cfg.device);
+}
+
+void HipCiphertextFactory::queueBatchedRealInput(std::vector<std::vector<double>> perInstance) const {
+  if (perInstance.size() != batch)
+    throw std::runtime_error("queueBatchedRealInput: expected " + std::to_string(batch) + " vectors, got " +
+                             std::to_string(perInstance.size()));
+  queuedRealInputs.push_back(std::move(perInstance));
+}
+
 void HipCiphertextFactory::queueBatchedInput(std::vector<std::vector<int64_t>> perInstance) const {
   if (perInstance.size() != batch)
     throw std::runtime_error("queueBatchedInput: expected " + std::to_string(batch) + " vectors, got " +
@@ -23,6 +38,7 @@ void HipCiphertextFactory::queueBatchedInput(std::vector<std::vector<int64_t>> p
 
 HipCiphertextFactory::~HipCiphertextFactory() {
   for (auto &e : plainCache) abc_hip_free(ctx, e.d_plain);
+  for (auto &e : ckksPlainCache) abc_hip_free(ctx, e.d_plain);
   abc_hip_ctx_destroy(ctx);
 }
 
@@ -39,32 +55,43 @@ const uint64_t *HipCiphertextFactory::cachedPlaintext(const std::vector<int> &va
 }
 
 void HipCiphertextFactory::setupContext(int device) {
-  // same parameter choice as SealCiphertextFactory::setupSealContext (SealCiphertextFactory.cpp:72-100)
   uint64_t primes[16];
-  const int count = abc_hip_default_bfv_primes(ciphertextSlotSize, primes);
-  if (count < 2) throw std::runtime_error(std::string("BFVDefault: ") + abc_hip_last_error());
-  const uint64_t t = abc_hip_plain_modulus_batching(ciphertextSlotSize, 20);
-  if (!t) throw std::runtime_error(std::string("PlainModulus::Batching: ") + abc_hip_last_error());
+  int count = 0;
+  uint64_t t = 0;
   int logn = 0;
   while ((1u << logn) < ciphertextSlotSize) ++logn;
-  abcHipCheck(abc_hip_ctx_create(ABC_HIP_SCHEME_BFV, logn, primes, count, t, device, &ctx), "context");
-  limbs = count - 1;
-  if (!keySeed) {  // fresh keys per factory, like seal::KeyGenerator
-    std::random_device rd;
-    keySeed = ((uint64_t)rd() << 32) ^ rd();
+  if (ckksMode) {
+    // seal::CoeffModulus::Create(N, bit_sizes): what a HAVE_SEAL_CKKS build of the reference would pass to its context
+    count = (int)ckksBits.size();
+    if (count > 16) throw std::runtime_error("HipCiphertextFactory: at most 16 primes");
+    abcHipCheck(abc_hip_create_primes(ciphertextSlotSize, ckksBits.data(), count, primes), "CoeffModulus::Create");
+  } else {
+    // same parameter choice as SealCiphertextFactory::setupSealContext (SealCiphertextFactory.cpp:72-100)
+    count = abc_hip_default_bfv_primes(ciphertextSlotSize, primes);
+    if (count < 2) throw std::runtime_error(std::string("BFVDefault: ") + abc_hip_last_error());
+    t = abc_hip_plain_modulus_batching(ciphertextSlotSize, 20);
+    if (!t) throw std::runtime_error(std::string("PlainModulus::Batching: ") + abc_hip_last_error());
   }
-  abcHipCheck(abc_hip_keygen(ctx, keySeed), "key generation");
+  abcHipCheck(abc_hip_ctx_create(ckksMode ? ABC_HIP_SCHEME_CKKS : ABC_HIP_SCHEME_BFV, logn, primes, count, t, device, &ctx), "context");
+  limbs = count - 1;
+  chain.assign(primes, primes + count);
+  if (ckksMode) ckksEncoder = CkksEncoder(ciphertextSlotSize, std::vector<uint64_t>(primes, primes + limbs));
+  // fresh keys per factory, like seal::KeyGenerator: OS-keyed ChaCha20 unless a TEST seed asks for the reproducible spec
+  if (keySeed) abcHipCheck(abc_hip_keygen(ctx, keySeed), "key generation");
+  else abcHipCheck(abc_hip_keygen_secure(ctx), "key generation");
 }
 
 template <typename T>
 std::vector<T> HipCiphertextFactory::expandVector(const std::vector<T> &values) const {
   std::vector<T> expanded(values.begin(), values.end());
-  if (expanded.size() > ciphertextSlotSize)
+  const size_t slots = usableSlots();
+  if (expanded.size() > slots)
     throw std::runtime_error("Cannot encode " + std::to_string(expanded.size()) + " elements in a ciphertext of size " +
-                             std::to_string(ciphertextSlotSize) + ". ");
+                             std::to_string(slots) + ". ");
+  if (expanded.empty()) throw std::runtime_error("Cannot encode an empty vector.");
   // fill up with the last given element (SealCiphertextFactory.cpp:112-114)
   const T last = expanded.back();
-  expanded.insert(expanded.end(), ciphertextSlotSize - expanded.size(), last);
+  expanded.insert(expanded.end(), slots - expanded.size(), last);
   return expanded;
 }
 
@@ -90,6 +117,15 @@ uint64_t *HipCiphertextFactory::createPlaintext(const std::vector<int> &value) c
 uint64_t *HipCiphertextFactory::createPlaintext(int64_t value) const { return createPlaintext(std::vector<int64_t>{value}); }
 
 std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCiphertext(const std::vector<int64_t> &data) const {
+  if (ckksMode) {
+    if (!queuedInputs.empty()) {  // integer batches queued for a CKKS factory: serve them as reals
+      std::vector<std::vector<double>> rows;
+      for (const auto &row : queuedInputs.front()) rows.emplace_back(row.begin(), row.end());
+      queuedInputs.pop_front();
+      queuedRealInputs.push_front(std::move(rows));
+    }
+    return createCkksCiphertext(std::vector<double>(data.begin(), data.end()));
+  }
   // B rows of N slots: the queued per-instance vectors if there are any, else B copies of `data`
   std::vector<int64_t> slots;
   slots.reserve(batch * ciphertextSlotSize);
@@ -112,13 +148,87 @@ std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCiphertext(const
   abc_hip_free(ctx, d_vals);
   if (rc) { abc_hip_free(ctx, d_plain); abcHipCheck(rc, "batch encode"); }
   auto ctxt = std::make_unique<HipCiphertext>(std::cref(*this));
-  static uint64_t encryptionCounter = 0;  // distinct randomness per encryption (instance i uses seed + i)
-  encryptionCounter += batch;
-  rc = abc_hip_encrypt(ctx, static_cast<const uint64_t *>(d_plain), keySeed * 0x9E3779B97F4A7C15ull + encryptionCounter,
-                       ctxt->devicePtr(), batch);
+  rc = encryptInto(d_plain, ctxt->devicePtr());
   abc_hip_free(ctx, d_plain);
   abcHipCheck(rc, "encrypt");
   return ctxt;
+}
+
+int HipCiphertextFactory::encryptInto(const void *d_plain, uint64_t *d_ct) const {
+  if (!keySeed) return abc_hip_encrypt_secure(ctx, static_cast<const uint64_t *>(d_plain), d_ct, batch);
+  // TEST seed given: reproducible randomness, distinct per encryption (instance i of this call uses seed + i)
+  static uint64_t encryptionCounter = 0;
+  encryptionCounter += batch;
+  return abc_hip_encrypt(ctx, static_cast<const uint64_t *>(d_plain), keySeed * 0x9E3779B97F4A7C15ull + encryptionCounter, d_ct, batch);
+}
+
+std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCiphertext(const std::vector<double> &data) const {
+  if (!ckksMode) throw std::runtime_error("Cannot create a ciphertext from real values: this factory uses BFV that only supports integers.");
+  return createCkksCiphertext(data);
+}
+
+std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCkksCiphertext(const std::vector<double> &data) const {
+  // B plaintexts [L][N]: encode on the host (floating point, off the hot path), forward transform + encryption on the device
+  const size_t N = ciphertextSlotSize, per = (size_t)limbs * N;
+  std::vector<uint64_t> coeffs(batch * per);
+  if (!queuedRealInputs.empty()) {
+    for (size_t b = 0; b < batch; ++b) ckksEncoder.encode(expandVector(queuedRealInputs.front()[b]), ckksScale, limbs, coeffs.data() + b * per);
+    queuedRealInputs.pop_front();
+  } else {
+    ckksEncoder.encode(expandVector(data), ckksScale, limbs, coeffs.data());
+    for (size_t b = 1; b < batch; ++b) std::copy(coeffs.begin(), coeffs.begin() + per, coeffs.begin() + b * per);
+  }
+  void *d_plain = nullptr;
+  abcHipCheck(abc_hip_malloc(ctx, &d_plain, coeffs.size() * 8), "plaintext allocation");
+  int rc = abc_hip_memcpy_h2d(ctx, d_plain, coeffs.data(), coeffs.size() * 8);
+  if (!rc) rc = abc_hip_ntt_limbs(ctx, static_cast<uint64_t *>(d_plain), limbs, batch, 0);
+  if (rc) { abc_hip_free(ctx, d_plain); abcHipCheck(rc, "CKKS encode"); }
+  auto ctxt = std::make_unique<HipCiphertext>(std::cref(*this));  // top level, default scale
+  rc = encryptInto(d_plain, ctxt->devicePtr());
+  abc_hip_free(ctx, d_plain);
+  abcHipCheck(rc, "encrypt");
+  return ctxt;
+}
+
+const uint64_t *HipCiphertextFactory::cachedCkksPlaintext(const std::vector<double> &value, int level, double scale) const {
+  for (const auto &e : ckksPlainCache)
+    if (e.level == level && e.scale == scale && e.values == value) return e.d_plain;
+  if (ckksPlainCache.size() >= kPlainCacheEntries) {
+    abc_hip_free(ctx, ckksPlainCache.front().d_plain);
+    ckksPlainCache.pop_front();
+  }
+  const size_t N = ciphertextSlotSize;
+  std::vector<uint64_t> coeffs((size_t)level * N);
+  ckksEncoder.encode(expandVector(value), scale, level, coeffs.data());
+  void *d_plain = nullptr;
+  abcHipCheck(abc_hip_malloc(ctx, &d_plain, coeffs.size() * 8), "plaintext allocation");
+  int rc = abc_hip_memcpy_h2d(ctx, d_plain, coeffs.data(), coeffs.size() * 8);
+  if (!rc) rc = abc_hip_ntt_limbs(ctx, static_cast<uint64_t *>(d_plain), level, 1, 0);
+  if (rc) { abc_hip_free(ctx, d_plain); abcHipCheck(rc, "CKKS encode"); }
+  ckksPlainCache.push_back(CachedCkksPlain{value, level, scale, static_cast<uint64_t *>(d_plain)});
+  return ckksPlainCache.back().d_plain;
+}
+
+void HipCiphertextFactory::decryptCiphertextRealBatch(AbstractCiphertext &abstractCiphertext, std::vector<std::vector<double>> &out) const {
+  if (!ckksMode) throw std::runtime_error("decryptCiphertextReal: not a CKKS factory");
+  const auto &ctxt = dynamic_cast<const HipCiphertext &>(abstractCiphertext);
+  const int nl = ctxt.level();
+  const size_t N = ciphertextSlotSize, per = (size_t)nl * N, bytes = batch * per * 8;
+  void *d_plain = nullptr;
+  abcHipCheck(abc_hip_malloc(ctx, &d_plain, bytes), "decrypt allocation");
+  int rc = abc_hip_decrypt(ctx, ctxt.devicePtr(), 2, nl, static_cast<uint64_t *>(d_plain), batch);
+  if (!rc) rc = abc_hip_ntt_limbs(ctx, static_cast<uint64_t *>(d_plain), nl, batch, 1);
+  std::vector<uint64_t> coeffs(batch * per);
+  if (!rc) rc = abc_hip_memcpy_d2h(ctx, coeffs.data(), d_plain, bytes);  // synchronises: result observable on return
+  abc_hip_free(ctx, d_plain);
+  abcHipCheck(rc, "decrypt");
+  out.assign(batch, {});
+  for (size_t b = 0; b < batch; ++b) ckksEncoder.decode(coeffs.data() + b * per, nl, ctxt.scale(), out[b]);
+}
+void HipCiphertextFactory::decryptCiphertextReal(AbstractCiphertext &abstractCiphertext, std::vector<double> &out) const {
+  std::vector<std::vector<double>> all;
+  decryptCiphertextRealBatch(abstractCiphertext, all);
+  out = std::move(all[0]);
 }
 std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCiphertext(const std::vector<int> &data) const {
   return createCiphertext(std::vector<int64_t>(data.begin(), data.end()));
@@ -131,6 +241,11 @@ std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCiphertext(std::
     const auto &v = ints->getData();
     return createCiphertext(std::vector<int64_t>(v.begin(), v.end()));
   }
+  if (ckksMode) {
+    if (auto d = dynamic_cast<Cleartext<double> *>(abstractValue.get())) return createCkksCiphertext(d->getData());
+    if (auto fl = dynamic_cast<Cleartext<float> *>(abstractValue.get()))
+      return createCkksCiphertext(std::vector<double>(fl->getData().begin(), fl->getData().end()));
+  }
   throw std::runtime_error(
       "Cannot create ciphertext from any other than a Cleartext<int> as used ciphertext factory (HipCiphertextFactory) uses BFV "
       "that only supports integers.");
@@ -138,6 +253,14 @@ std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::createCiphertext(std::
 
 void HipCiphertextFactory::decryptCiphertextBatch(AbstractCiphertext &abstractCiphertext,
                                                   std::vector<std::vector<int64_t>> &out) const {
+  if (ckksMode) {  // the interface speaks int64: nearest integers of the decoded slots
+    std::vector<std::vector<double>> real;
+    decryptCiphertextRealBatch(abstractCiphertext, real);
+    out.assign(real.size(), {});
+    for (size_t b = 0; b < real.size(); ++b)
+      for (double v : real[b]) out[b].push_back((int64_t)std::llrint(v));
+    return;
+  }
   auto &ctxt = dynamic_cast<HipCiphertext &>(abstractCiphertext);
   const size_t words = batch * ciphertextSlotSize, bytes = words * 8;
   void *d_plain = nullptr, *d_vals = nullptr;

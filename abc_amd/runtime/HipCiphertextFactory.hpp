@@ -9,9 +9,25 @@
 #include <string>
 #include <vector>
 
+#include "CkksEncoder.hpp"
 #include "plugin_api.hpp"
 
 struct abc_hip_ctx;
+
+// Scheme policy of a HipCiphertextFactory.  The default is the reference's own choice (BFV, BFVDefault(N), Batching(N, 20):
+// SealCiphertextFactory.cpp:72-100).  CKKS is the hook the reference left open (CMakeLists.txt:216, HAVE_SEAL_CKKS): a
+// modulus chain given by bit sizes (data limbs, then the special prime) and a default scale.  The caller of the plugin
+// surface needs nothing else: levels and scales are tracked per ciphertext, ct x ct and ct x plain products are rescaled
+// (one limb dropped) while limbs remain, and operands at different levels are brought to the lower one.
+struct HipSchemeConfig {
+  bool ckks = false;
+  unsigned int ringDegree = 16'384;
+  std::vector<int> ckksBits = {50, 40, 40, 40, 50};  // the benchmark chain
+  double ckksScale = 1099511627776.0;                // 2^40
+  int device = 0;
+  uint64_t seed = 0;  // 0: keys and encryption randomness from the OS-keyed generator; else the reproducible TEST spec
+  size_t batch = 1;
+};
 
 class HipCiphertextFactory : public AbstractCiphertextFactory {
   const unsigned int ciphertextSlotSize = 16'384;
@@ -23,6 +39,7 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
   // ONE pass of an unchanged interpreter (ABC's RuntimeVisitor or CircuitRuntime) evaluates the circuit on B input sets.
   size_t batch = 1;
   mutable std::deque<std::vector<std::vector<int64_t>>> queuedInputs;
+  mutable std::deque<std::vector<std::vector<double>>> queuedRealInputs;
   // Encoded plaintexts of recent plain operands (the reference re-encodes its operand on every plain operation,
   // SealCiphertext.cpp:132,143,154: here a repeated constant costs one encode + upload, and no device synchronisation)
   struct CachedPlain {
@@ -32,13 +49,30 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
   mutable std::deque<CachedPlain> plainCache;
   static constexpr size_t kPlainCacheEntries = 32;
 
+  // CKKS policy (empty / unused for BFV)
+  bool ckksMode = false;
+  double ckksScale = 0;
+  std::vector<int> ckksBits;
+  std::vector<uint64_t> chain;  // the context's primes: data limbs, then the special prime
+  CkksEncoder ckksEncoder;
+  struct CachedCkksPlain {
+    std::vector<double> values;
+    int level;
+    double scale;
+    uint64_t *d_plain;
+  };
+  mutable std::deque<CachedCkksPlain> ckksPlainCache;
+
   void setupContext(int device);
   template <typename T>
   std::vector<T> expandVector(const std::vector<T> &values) const;
+  std::unique_ptr<AbstractCiphertext> createCkksCiphertext(const std::vector<double> &data) const;
+  int encryptInto(const void *d_plain, uint64_t *d_ct) const;
 
  public:
   HipCiphertextFactory();
   explicit HipCiphertextFactory(unsigned int numElementsPerCiphertextSlot, int device = 0, uint64_t seed = 0, size_t batchSize = 1);
+  explicit HipCiphertextFactory(const HipSchemeConfig &config);
   virtual ~HipCiphertextFactory();  // (ABC's AbstractCiphertextFactory declares no virtual destructor)
   HipCiphertextFactory(const HipCiphertextFactory &) = delete;  // one device context per factory
   HipCiphertextFactory &operator=(const HipCiphertextFactory &) = delete;
@@ -48,6 +82,20 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
   [[nodiscard]] int dataLimbs() const { return limbs; }
   [[nodiscard]] size_t batchSize() const { return batch; }
   [[nodiscard]] size_t ciphertextWords() const { return batch * 2 * limbs * ciphertextSlotSize; }  // of one (batched) value
+  [[nodiscard]] size_t ciphertextWords(int level) const { return batch * 2 * (size_t)level * ciphertextSlotSize; }
+  [[nodiscard]] bool isCkks() const { return ckksMode; }
+  [[nodiscard]] double defaultScale() const { return ckksScale; }
+  [[nodiscard]] uint64_t prime(int j) const { return chain[j]; }
+  // slots a value may fill: N for BFV (two rows of N/2), N/2 for CKKS (one row; rotateRows rotates it cyclically)
+  [[nodiscard]] unsigned int usableSlots() const { return ckksMode ? ciphertextSlotSize / 2 : ciphertextSlotSize; }
+  // CKKS: device plaintext [level][N] (NTT form) of public values at a given level and scale, from the factory's cache
+  const uint64_t *cachedCkksPlaintext(const std::vector<double> &value, int level, double scale) const;
+  // CKKS: all slot values of instance 0 as doubles (decryptCiphertext rounds them to the interface's int64)
+  void decryptCiphertextReal(AbstractCiphertext &abstractCiphertext, std::vector<double> &out) const;
+  void decryptCiphertextRealBatch(AbstractCiphertext &abstractCiphertext, std::vector<std::vector<double>> &out) const;
+  // batch mode for real-valued inputs (CKKS)
+  void queueBatchedRealInput(std::vector<std::vector<double>> perInstance) const;
+  std::unique_ptr<AbstractCiphertext> createCiphertext(const std::vector<double> &data) const;
 
   // Batch mode: the next createCiphertext call encrypts these B vectors (one per circuit instance) instead of B copies
   // of its argument; calls are served in queue order, i.e. in the order the interpreter declares its secret inputs.

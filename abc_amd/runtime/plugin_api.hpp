@@ -161,8 +161,29 @@ class Cleartext : public ICleartext {
     data[idx] = v->getData().at(0);
   }
 
+  // public - secret, done right: encrypt the public operand with the ciphertext's factory, subtract, RETURN the ciphertext.
+  // Upstream's Cleartext<int>::subtract_inplace builds exactly this value and then drops it, because an in-place operator
+  // on a Cleartext cannot turn the receiver into a ciphertext (include/ast_opt/runtime/Cleartext.h:349-360): its `1 --- c`
+  // silently leaves the cleartext unchanged.  Deviation, documented in INTEGRATION.md: here the in-place form refuses
+  // (it cannot deliver the result) and this method delivers it; CircuitRuntime uses it for `public - secret`.
+  [[nodiscard]] std::unique_ptr<AbstractCiphertext> subtractCiphertext(const AbstractCiphertext &secret) const {
+    if constexpr (std::is_same<T, int>::value) {
+      std::unique_ptr<AbstractCiphertext> lhs = secret.getFactory().createCiphertext(data);
+      lhs->subtractInplace(secret);
+      return lhs;
+    } else {
+      throw std::runtime_error("public - secret is defined for Cleartext<int> only.");
+    }
+  }
+
   void add_inplace(const AbstractValue &o) override { zipWith(std::plus<T>(), o); }
-  void subtract_inplace(const AbstractValue &o) override { zipWith(std::minus<T>(), o); }
+  void subtract_inplace(const AbstractValue &o) override {
+    if (dynamic_cast<const AbstractCiphertext *>(&o))
+      throw std::runtime_error(
+          "Cleartext - AbstractCiphertext cannot be computed in place (the result is a ciphertext): use "
+          "Cleartext<int>::subtractCiphertext, which returns it.");
+    zipWith(std::minus<T>(), o);
+  }
   void multiply_inplace(const AbstractValue &o) override { zipWith(std::multiplies<T>(), o); }
   void divide_inplace(const AbstractValue &o) override {
     if constexpr (std::is_same<T, bool>::value) throw std::invalid_argument("Cannot divide_inplace booleans.");
@@ -170,6 +191,7 @@ class Cleartext : public ICleartext {
   }
   void modulo_inplace(const AbstractValue &o) override {
     if constexpr (std::is_same<T, bool>::value) throw std::invalid_argument("Cannot modulo_inplace booleans.");
+    else if constexpr (std::is_floating_point<T>::value) throw std::runtime_error("Cannot apply modulo to operands of a floating-point type.");
     else zipWith(std::modulus<T>(), o);
   }
   void logicalAnd_inplace(const AbstractValue &o) override { zipWith(std::logical_and<T>(), o); }
@@ -180,12 +202,22 @@ class Cleartext : public ICleartext {
   void logicalGreaterEqual_inplace(const AbstractValue &o) override { zipWith(std::greater_equal<T>(), o); }
   void logicalEqual_inplace(const AbstractValue &o) override { zipWith(std::equal_to<T>(), o); }
   void logicalNotEqual_inplace(const AbstractValue &o) override { zipWith(std::not_equal_to<T>(), o); }
-  void bitwiseAnd_inplace(const AbstractValue &o) override { zipWith(std::bit_and<T>(), o); }
-  void bitwiseXor_inplace(const AbstractValue &o) override { zipWith(std::bit_xor<T>(), o); }
-  void bitwiseOr_inplace(const AbstractValue &o) override { zipWith(std::bit_or<T>(), o); }
+  void bitwiseAnd_inplace(const AbstractValue &o) override {
+    if constexpr (std::is_floating_point<T>::value) throw std::runtime_error("Cannot apply a bitwise operator to operands of a floating-point type.");
+    else zipWith(std::bit_and<T>(), o);
+  }
+  void bitwiseXor_inplace(const AbstractValue &o) override {
+    if constexpr (std::is_floating_point<T>::value) throw std::runtime_error("Cannot apply a bitwise operator to operands of a floating-point type.");
+    else zipWith(std::bit_xor<T>(), o);
+  }
+  void bitwiseOr_inplace(const AbstractValue &o) override {
+    if constexpr (std::is_floating_point<T>::value) throw std::runtime_error("Cannot apply a bitwise operator to operands of a floating-point type.");
+    else zipWith(std::bit_or<T>(), o);
+  }
   void logicalNot_inplace() override { for (auto it = data.begin(); it != data.end(); ++it) *it = !*it; }
   void bitwiseNot_inplace() override {
     if constexpr (std::is_same<T, bool>::value) { for (auto it = data.begin(); it != data.end(); ++it) *it = !*it; }
+    else if constexpr (std::is_floating_point<T>::value) throw std::runtime_error("Cannot apply bitwise-NOT to an operand of a floating-point type.");
     else { for (auto &v : data) v = ~v; }
   }
 };

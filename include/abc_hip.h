@@ -77,7 +77,14 @@ int abc_hip_memcpy_d2h(abc_hip_ctx *ctx, void *h_dst, const void *d_src, size_t 
 int abc_hip_memcpy_d2d(abc_hip_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 
 /* ---- keys: replaces seal::KeyGenerator use at SealCiphertextFactory.cpp:89-93 ---- */
-/* generate sk, pk, relin key and all default Galois keys on the device from `seed` */
+/* generate sk, pk, relin key and all default Galois keys on the device.
+ * abc_hip_keygen_secure: what a deployment uses (and HipCiphertextFactory's default): secret key and errors from ChaCha20
+ * keyed with 256 bits of getrandom(2), the published uniform polynomials from an independently keyed stream, secret
+ * temporaries wiped before release.
+ * abc_hip_keygen(seed): TEST ONLY -- the repo's reproducible sampling spec (splitmix64-seeded xoshiro256**),
+ * which the CPU oracle implements too so that keys are bit-comparable; a 64-bit seed and a linear generator are not
+ * cryptographic strength. */
+int abc_hip_keygen_secure(abc_hip_ctx *ctx);
 int abc_hip_keygen(abc_hip_ctx *ctx, uint64_t seed);
 /* or load externally generated keys (host pointers) */
 int abc_hip_load_secret_key(abc_hip_ctx *ctx, const uint64_t *h_sk /*[L+1][N] NTT*/);
@@ -98,7 +105,10 @@ uint32_t abc_hip_galois_elt_from_step(abc_hip_ctx *ctx, int step);
 int abc_hip_batch_encode(abc_hip_ctx *ctx, const int64_t *d_values, uint64_t *d_plain, size_t count);
 /* seal::BatchEncoder::decode (SealCiphertextFactory.cpp:151) */
 int abc_hip_batch_decode(abc_hip_ctx *ctx, const uint64_t *d_plain, int64_t *d_values, size_t count);
-/* seal::Encryptor::encrypt, public key (SealCiphertextFactory.cpp:12); ciphertext i uses seed+i */
+/* seal::Encryptor::encrypt, public key (SealCiphertextFactory.cpp:12).
+ * abc_hip_encrypt_secure: encryption randomness from a freshly OS-keyed ChaCha20 stream per call (never derived from a
+ * key seed), wiped afterwards.  abc_hip_encrypt(seed): TEST ONLY, ciphertext i uses the reproducible stream seed+i. */
+int abc_hip_encrypt_secure(abc_hip_ctx *ctx, const uint64_t *d_plain, uint64_t *d_ct, size_t count);
 int abc_hip_encrypt(abc_hip_ctx *ctx, const uint64_t *d_plain, uint64_t seed, uint64_t *d_ct, size_t count);
 /* seal::Decryptor::decrypt (SealCiphertextFactory.cpp:150); size = 2 or 3 polynomials */
 int abc_hip_decrypt(abc_hip_ctx *ctx, const uint64_t *d_ct, int size, int nl, uint64_t *d_plain, size_t count);
