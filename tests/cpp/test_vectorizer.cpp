@@ -1,0 +1,198 @@
+// CircuitVectorizer: the reference's (DISABLED, unfinished) VectorizerTest cases as text goldens, and execution of the
+// produced circuits -- on a cleartext slot model here (mode "cpu") and on the HIP backend (default mode, needs a GPU).
+#include <sstream>
+
+#include "CircuitRuntime.hpp"
+#include "CircuitVectorizer.hpp"
+#include "mini_test.hpp"
+#ifndef VECTORIZER_CPU_ONLY
+#include "HipCiphertext.hpp"
+#include "HipCiphertextFactory.hpp"
+#endif
+
+// ---- test-only cleartext model of a batched ciphertext: N slots in two rows, pad with the last value, cyclic row rotation ----
+class SlotFactory;
+class SlotCiphertext : public AbstractCiphertext {
+ public:
+  std::vector<int64_t> v;
+  explicit SlotCiphertext(const std::reference_wrapper<const AbstractCiphertextFactory> f) : AbstractCiphertext(f) {}
+  SlotCiphertext(const SlotCiphertext &o) : AbstractCiphertext(o.factory), v(o.v) {}
+  static const SlotCiphertext &of(const AbstractCiphertext &c) { return dynamic_cast<const SlotCiphertext &>(c); }
+  std::vector<int64_t> plain(const ICleartext &c) const {
+    auto p = dynamic_cast<const Cleartext<int> *>(&c);
+    if (!p) throw std::runtime_error("Cleartext<int> expected");
+    std::vector<int64_t> r(p->getData().begin(), p->getData().end());
+    r.resize(v.size(), r.back());
+    return r;
+  }
+  template <class F> void zip(const std::vector<int64_t> &r, F f) { for (size_t i = 0; i < v.size(); ++i) v[i] = f(v[i], r[i]); }
+  std::unique_ptr<SlotCiphertext> copy() const { return std::make_unique<SlotCiphertext>(*this); }
+#define SLOT_OP(name, expr)                                                                                                   \
+  std::unique_ptr<AbstractCiphertext> name(const AbstractCiphertext &o) const override { auto r = copy(); r->name##Inplace(o); return r; } \
+  void name##Inplace(const AbstractCiphertext &o) override { zip(of(o).v, [](int64_t a, int64_t b) { return expr; }); }     \
+  std::unique_ptr<AbstractCiphertext> name##Plain(const ICleartext &o) const override { auto r = copy(); r->name##PlainInplace(o); return r; } \
+  void name##PlainInplace(const ICleartext &o) override { zip(plain(o), [](int64_t a, int64_t b) { return expr; }); }
+  SLOT_OP(multiply, a * b)
+  SLOT_OP(add, a + b)
+  SLOT_OP(subtract, a - b)
+#undef SLOT_OP
+  std::unique_ptr<AbstractCiphertext> rotateRows(int steps) const override { auto r = copy(); r->rotateRowsInplace(steps); return r; }
+  void rotateRowsInplace(int steps) override {
+    const size_t row = v.size() / 2;
+    std::vector<int64_t> r(v.size());
+    for (size_t i = 0; i < row; ++i) {
+      const size_t src = (i + (size_t)((steps % (int)row + (int)row) % (int)row)) % row;
+      r[i] = v[src];
+      r[row + i] = v[row + src];
+    }
+    v.swap(r);
+  }
+  std::unique_ptr<AbstractCiphertext> clone() const override { return copy(); }
+  void add_inplace(const AbstractValue &o) override { if (auto c = dynamic_cast<const AbstractCiphertext *>(&o)) addInplace(*c); else addPlainInplace(dynamic_cast<const ICleartext &>(o)); }
+  void subtract_inplace(const AbstractValue &o) override { if (auto c = dynamic_cast<const AbstractCiphertext *>(&o)) subtractInplace(*c); else subtractPlainInplace(dynamic_cast<const ICleartext &>(o)); }
+  void multiply_inplace(const AbstractValue &o) override { if (auto c = dynamic_cast<const AbstractCiphertext *>(&o)) multiplyInplace(*c); else multiplyPlainInplace(dynamic_cast<const ICleartext &>(o)); }
+#define SLOT_NO(name) void name(const AbstractValue &) override { throw std::runtime_error("unsupported"); }
+  SLOT_NO(divide_inplace) SLOT_NO(modulo_inplace) SLOT_NO(logicalAnd_inplace) SLOT_NO(logicalOr_inplace) SLOT_NO(logicalLess_inplace)
+  SLOT_NO(logicalLessEqual_inplace) SLOT_NO(logicalGreater_inplace) SLOT_NO(logicalGreaterEqual_inplace) SLOT_NO(logicalEqual_inplace)
+  SLOT_NO(logicalNotEqual_inplace) SLOT_NO(bitwiseAnd_inplace) SLOT_NO(bitwiseXor_inplace) SLOT_NO(bitwiseOr_inplace)
+#undef SLOT_NO
+  void logicalNot_inplace() override { throw std::runtime_error("unsupported"); }
+  void bitwiseNot_inplace() override { throw std::runtime_error("unsupported"); }
+};
+class SlotFactory : public AbstractCiphertextFactory {
+  size_t n;
+ public:
+  explicit SlotFactory(size_t slots) : n(slots) {}
+  std::unique_ptr<AbstractCiphertext> createCiphertext(const std::vector<int64_t> &d) const override {
+    auto c = std::make_unique<SlotCiphertext>(std::cref(static_cast<const AbstractCiphertextFactory &>(*this)));
+    c->v = d;
+    c->v.resize(n, d.back());
+    return c;
+  }
+  std::unique_ptr<AbstractCiphertext> createCiphertext(const std::vector<int> &d) const override { return createCiphertext(std::vector<int64_t>(d.begin(), d.end())); }
+  std::unique_ptr<AbstractCiphertext> createCiphertext(int64_t d) const override { return createCiphertext(std::vector<int64_t>{d}); }
+  std::unique_ptr<AbstractCiphertext> createCiphertext(std::unique_ptr<AbstractValue> &&c) const override {
+    auto p = dynamic_cast<Cleartext<int> *>(c.get());
+    if (!p) throw std::runtime_error("Cleartext<int> expected");
+    return createCiphertext(p->getData());
+  }
+  void decryptCiphertext(AbstractCiphertext &c, std::vector<int64_t> &out) const override { out = SlotCiphertext::of(c).v; }
+  std::string getString(AbstractCiphertext &) const override { return ""; }
+};
+
+static std::string squash(const std::string &s) {  // whitespace-insensitive comparison
+  std::string r;
+  for (char ch : s)
+    if (!std::isspace((unsigned char)ch)) r += ch;
+  return r;
+}
+static std::string listOf(const std::vector<int> &v) {
+  std::ostringstream os;
+  os << "{";
+  for (size_t i = 0; i < v.size(); ++i) os << (i ? ", " : "") << v[i];
+  os << "}";
+  return os.str();
+}
+static int64_t slot0(AbstractCiphertextFactory &f, const std::string &inputs, const std::string &program, const std::string &var, size_t slot = 0) {
+  CircuitRuntime rt(f, inputs);
+  rt.executeAst(program);
+  auto out = rt.getOutput("y = " + var + ";");
+  std::vector<int64_t> v;
+  f.decryptCiphertext(*dynamic_cast<AbstractCiphertext *>(out[0].second.get()), v);
+  return v.at(slot);
+}
+
+static void runAll(MiniTest &t, AbstractCiphertextFactory &f, const char *backend) {
+  const std::vector<int> x = {3, 1, 4, 1, 5, 9, 2, 6, 5, 3}, y = {2, 7, 1, 8, 2, 8, 1, 8, 2, 8};
+  auto name = [&](const char *n) { return std::string(n) + " [" + backend + "]"; };
+  t.run(name("sum of 8 slots: rotate-and-add tree, result in slot 0").c_str(), [&] {
+    CircuitVectorizer v({"sum"});
+    std::string prog;
+    for (int i = 0; i < 8; ++i) prog += "sum = sum + x[" + std::to_string(i) + "];\n";
+    const std::string vec = v.vectorize(prog);
+    EXPECT_TRUE(v.reductionRuns == 1);
+    EXPECT_TRUE(squash(vec) == squash("secret int __vt0__ = x; __vt0__ = __vt0__ +++ rotate(__vt0__, 4); __vt0__ = __vt0__ +++ rotate(__vt0__, 2);"
+                                      "__vt0__ = __vt0__ +++ rotate(__vt0__, 1); sum = sum +++ __vt0__;"));
+    const std::string in = "secret int x = " + listOf(std::vector<int>(x.begin(), x.begin() + 8)) + "; secret int sum = {100};";
+    EXPECT_TRUE(slot0(f, in, vec, "sum") == 100 + 3 + 1 + 4 + 1 + 5 + 9 + 2 + 6);
+  });
+  t.run(name("sum of 10 slots: masked to 10, tree over 16").c_str(), [&] {
+    CircuitVectorizer v({"sum"});
+    std::string prog;
+    for (int i = 0; i < 10; ++i) prog += "sum = sum + x[" + std::to_string(i) + "];\n";
+    const std::string vec = v.vectorize(prog);
+    EXPECT_TRUE(vec.find("*** {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0}") != std::string::npos);
+    EXPECT_TRUE(vec.find("rotate(__vt0__, 8)") != std::string::npos);
+    const std::string in = "secret int x = " + listOf(x) + "; secret int sum = {0};";
+    EXPECT_TRUE(slot0(f, in, vec, "sum") == 39);
+  });
+  t.run(name("dot product: sum = sum + x[i] * y[i]").c_str(), [&] {
+    CircuitVectorizer v({"acc"});
+    std::string prog;
+    int64_t want = 0;
+    for (int i = 0; i < 8; ++i) { prog += "acc = acc + x[" + std::to_string(i) + "] * y[" + std::to_string(i) + "];\n"; want += x[i] * y[i]; }
+    const std::string vec = v.vectorize(prog);
+    EXPECT_TRUE(vec.find("secret int __vt0__ = x * y;") != std::string::npos);
+    const std::string in = "secret int x = " + listOf(std::vector<int>(x.begin(), x.begin() + 8)) + "; secret int y = " +
+                           listOf(std::vector<int>(y.begin(), y.begin() + 8)) + "; secret int acc = {0};";
+    EXPECT_TRUE(slot0(f, in, vec, "acc") == want);
+  });
+  t.run(name("element-wise run with an outlier, executed").c_str(), [&] {
+    CircuitVectorizer v;
+    std::string prog;
+    for (int i = 0; i < 9; ++i) prog += "z[" + std::to_string(i) + "] = x[" + std::to_string(i) + "] + y[" + std::to_string(i) + "];\n";
+    prog += "z[9] = 5;\n";
+    const std::string vec = v.vectorize(prog);
+    const std::string in = "secret int x = " + listOf(x) + "; secret int y = " + listOf(y) + "; secret int z = {0};";
+    for (size_t i = 0; i < 9; ++i) EXPECT_TRUE(slot0(f, in, vec, "z", i) == x[i] + y[i]);
+    EXPECT_TRUE(slot0(f, in, vec, "z", 9) == 5);
+  });
+}
+
+int main(int argc, char **argv) {
+  MiniTest t;
+  // ---- text goldens: test/visitor/VectorizerTest.cpp ----
+  t.run("trivialVectors (VectorizerTest.cpp:7-38): x[i] = y[i], i = 0..9  ->  x = y", [] {
+    CircuitVectorizer v;
+    std::string prog;
+    for (int i = 0; i < 10; ++i) prog += "x[" + std::to_string(i) + "] = y[" + std::to_string(i) + "];\n";
+    EXPECT_TRUE(squash(v.vectorize(prog)) == "x=y;");
+    EXPECT_TRUE(v.elementwiseRuns == 1);
+  });
+  t.run("trivialInterleavedVectors (:64-94): two interleaved runs are separated", [] {
+    CircuitVectorizer v;
+    std::string prog;
+    for (int i = 0; i < 4; ++i) prog += "x[" + std::to_string(i) + "] = y[" + std::to_string(i) + "];\na[" + std::to_string(i) + "] = b[" + std::to_string(i) + "];\n";
+    EXPECT_TRUE(squash(v.vectorize(prog)) == "x=y;a=b;");
+  });
+  t.run("singleOutlierVector (:96-124): mask multiply + constant add", [] {
+    CircuitVectorizer v;
+    std::string prog;
+    for (int i = 0; i < 9; ++i) prog += "x[" + std::to_string(i) + "] = y[" + std::to_string(i) + "];\n";
+    prog += "x[9] = 5;\n";
+    EXPECT_TRUE(squash(v.vectorize(prog)) == squash("x = y; x = x *** {1,1,1,1,1,1,1,1,1,0}; x = x +++ {0,0,0,0,0,0,0,0,0,5};"));
+  });
+  t.run("what does not batch passes through untouched, in order", [] {
+    CircuitVectorizer v({"s"});
+    const std::string prog = "x[0] = y[0];\nx[1] = y[1] * 2;\nq = q + 1;\ns = s + a[0];\ns = s + b[1];\n";
+    EXPECT_TRUE(squash(v.vectorize(prog)) == squash(prog));
+    EXPECT_TRUE(v.elementwiseRuns == 0 && v.reductionRuns == 0);
+    // a run is closed before a statement that reads its target
+    const std::string prog2 = "x[0] = y[0];\nx[1] = y[1];\nw = x;\nx[2] = y[2];\n";
+    EXPECT_TRUE(squash(v.vectorize(prog2)) == squash("x = y; w = x; x[2] = y[2];"));
+    // for loops and expression lists survive the statement splitter
+    const std::string prog3 = "for (int i = 0; i < 3; i = i + 1) { r = r + {1, 2}; }\nx[0] = y[0];\nx[1] = y[1];\n";
+    EXPECT_TRUE(squash(v.vectorize(prog3)) == squash("for (int i = 0; i < 3; i = i + 1) { r = r + {1, 2}; } x = y;"));
+  });
+  SlotFactory model(64);
+  runAll(t, model, "cleartext slot model");
+#ifndef VECTORIZER_CPU_ONLY
+  if (!(argc > 1 && std::string(argv[1]) == "cpu")) {
+    HipCiphertextFactory hipf(4096, 0, 0xABC0F4ull);
+    runAll(t, hipf, "HIP backend, BFV N=4096");
+  }
+#else
+  (void)argc; (void)argv;
+#endif
+  return t.summary();
+}
