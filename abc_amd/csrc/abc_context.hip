@@ -646,17 +646,37 @@ int abc_hip_sync(abc_hip_ctx *c) {
 // flushed by abc_hip_trim, when the cap is reached, and whenever a hipMalloc of this context fails.
 // (hipMallocAsync / hipFreeAsync were tried first and returned wrong results on some boxes of this pool when two
 // contexts alternated -- analysis in DESIGN.md section 4b; ABC_HIP_SYNC_ALLOC=1 turns the cache off.)
+static void *const kCapturing = (void *)(uintptr_t)1;
+
 int abc_hip_malloc(abc_hip_ctx *c, void **d_ptr, size_t bytes) {
   CTX_GUARD(c);
   if (!bytes) bytes = 8;
   if (c->cache_alloc) {
     std::lock_guard<std::mutex> lock(c->alloc_mu);
+    if (c->capture_active) {
+      // inside a capture: a block born and freed in this capture first (safe: stream order inside the graph), then the
+      // cache; never the driver (hipMalloc is not capturable) -- the sequence must have run once eagerly before
+      auto cf = c->cap_free.find(bytes);
+      if (cf != c->cap_free.end() && !cf->second.empty()) {
+        *d_ptr = cf->second.back();
+        cf->second.pop_back();
+        return 0;
+      }
+    }
     auto it = c->free_blocks.find(bytes);
     if (it != c->free_blocks.end() && !it->second.empty()) {
       *d_ptr = it->second.back();
       it->second.pop_back();
       c->cached_bytes -= bytes;
+      if (c->capture_active) {
+        c->pin[*d_ptr] = kCapturing;
+        c->cap_born[*d_ptr] = true;
+      }
       return 0;
+    }
+    if (c->capture_active) {
+      set_error("allocation during graph capture found no cached buffer: run the sequence once eagerly first");
+      return 1;
     }
   }
   ABC_HIP_CHECK(malloc_retry(c, d_ptr, bytes));
@@ -675,6 +695,19 @@ int abc_hip_free(abc_hip_ctx *c, void *d_ptr) {
       std::lock_guard<std::mutex> lock(c->alloc_mu);
       auto it = c->block_size.find(d_ptr);
       if (it != c->block_size.end()) {
+        if (c->capture_active) {
+          if (c->cap_born.count(d_ptr)) {  // an intermediate of the circuit being recorded
+            c->cap_free[it->second].push_back(d_ptr);
+          } else {  // existed before: the graph reads it as an input on every replay -- pinned, never reused
+            c->pin[d_ptr] = kCapturing;
+            c->parked[d_ptr] = true;
+          }
+          return 0;
+        }
+        if (c->pin.count(d_ptr)) {  // baked into a live graph: parked until abc_hip_graph_destroy
+          c->parked[d_ptr] = true;
+          return 0;
+        }
         if (c->cached_bytes + it->second <= c->cache_cap) {
           c->free_blocks[it->second].push_back(d_ptr);
           c->cached_bytes += it->second;
@@ -932,16 +965,50 @@ int abc_hip_keyswitch(abc_hip_ctx *c, const uint64_t *target, uint32_t key_kind,
 int abc_hip_graph_begin(abc_hip_ctx *c) {
   CTX_GUARD(c);
   ABC_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  std::lock_guard<std::mutex> lock(c->alloc_mu);
+  c->capture_active = true;
   return 0;
+}
+// hand every block the finished (or abandoned) capture touched to `owner`; owner = nullptr releases them
+static void settle_capture(abc_hip_ctx *c, void *owner) {
+  std::lock_guard<std::mutex> lock(c->alloc_mu);
+  c->capture_active = false;
+  for (auto &kv : c->cap_free)
+    for (void *p : kv.second) c->parked[p] = true;  // born and freed inside the capture: nobody holds them any more
+  c->cap_free.clear();
+  c->cap_born.clear();
+  std::vector<void *> mine;
+  for (auto &kv : c->pin)
+    if (kv.second == kCapturing) mine.push_back(kv.first);
+  for (void *p : mine) {
+    if (owner) {
+      c->pin[p] = owner;
+    } else {
+      c->pin.erase(p);
+      if (c->parked.erase(p)) {
+        const size_t sz = c->block_size[p];
+        c->free_blocks[sz].push_back(p);
+        c->cached_bytes += sz;
+      }
+    }
+  }
 }
 int abc_hip_graph_end(abc_hip_ctx *c, void **out) {
   CTX_GUARD(c);
   hipGraph_t graph = nullptr;
-  ABC_HIP_CHECK(hipStreamEndCapture(c->stream, &graph));
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
   hipGraphExec_t exec = nullptr;
-  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (e != hipSuccess) { set_error(std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); return 1; }
+  if (e == hipSuccess) {
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    settle_capture(c, nullptr);
+    set_error(std::string("graph capture failed: ") + hipGetErrorString(e));
+    return 1;
+  }
+  settle_capture(c, (void *)exec);
   *out = exec;
   return 0;
 }
@@ -954,6 +1021,18 @@ int abc_hip_graph_destroy(abc_hip_ctx *c, void *exec) {
   CTX_GUARD(c);
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   ABC_HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)exec));
+  std::lock_guard<std::mutex> lock(c->alloc_mu);
+  std::vector<void *> mine;
+  for (auto &kv : c->pin)
+    if (kv.second == exec) mine.push_back(kv.first);
+  for (void *p : mine) {  // unpin; what the caller had already freed goes back to the cache now
+    c->pin.erase(p);
+    if (c->parked.erase(p)) {
+      const size_t sz = c->block_size[p];
+      c->free_blocks[sz].push_back(p);
+      c->cached_bytes += sz;
+    }
+  }
   return 0;
 }
 

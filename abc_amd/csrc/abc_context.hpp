@@ -127,6 +127,15 @@ struct abc_hip_ctx {
   size_t cached_bytes = 0, cache_cap = (size_t)8 << 30;
   std::unordered_map<size_t, std::vector<void *>> free_blocks;  // size -> cached blocks
   std::unordered_map<void *, size_t> block_size;                 // every live block handed out by abc_hip_malloc
+  // Blocks a recorded circuit (abc_hip_graph_*) has baked into its kernel arguments are PINNED to it: while the graph exists
+  // they never go back to the free list, whoever frees them.  pin: block -> owning graph (kCapturing until graph_end names it);
+  // parked: pinned blocks the caller has already freed (released to the cache when the graph is destroyed);
+  // cap_free: blocks allocated AND freed during the running capture, reusable inside it (stream order inside the graph).
+  bool capture_active = false;
+  std::unordered_map<void *, void *> pin;
+  std::unordered_map<void *, bool> parked;
+  std::unordered_map<size_t, std::vector<void *>> cap_free;
+  std::unordered_map<void *, bool> cap_born;  // allocated during the running capture
   bool use_fp = true;  // fp64 transforms for primes < 2^50 (ABC_HIP_NO_FP64=1 forces the integer path)
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.

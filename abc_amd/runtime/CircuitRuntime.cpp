@@ -3,6 +3,8 @@
 #include <cctype>
 #include <iostream>
 
+#include "GraphCapable.hpp"
+
 namespace {
 typedef CircuitRuntime::Token Token;
 
@@ -408,4 +410,64 @@ void CircuitRuntime::printOutput(const std::string &outputs, std::ostream &targe
     if (auto c = dynamic_cast<AbstractCiphertext *>(v.second.get())) target << factory.getString(*c) << std::endl;
     else if (auto p = dynamic_cast<ICleartext *>(v.second.get())) target << p->toString() << std::endl;
   }
+}
+
+// ---- recorded circuits ----
+std::map<std::string, CircuitRuntime::Variable> CircuitRuntime::snapshot() const {
+  std::map<std::string, Variable> copy;
+  for (const auto &kv : vars) {
+    Variable v;
+    v.secret = kv.second.secret;
+    if (kv.second.ctxt) v.ctxt = kv.second.ctxt->clone();  // copy-on-write reference
+    if (kv.second.clear) v.clear = kv.second.clear->clone();
+    copy.emplace(kv.first, std::move(v));
+  }
+  return copy;
+}
+
+CircuitRuntime::~CircuitRuntime() {
+  if (graph)
+    if (auto g = dynamic_cast<const GraphCapable *>(&factory)) {
+      try { g->graphDestroy(graph); } catch (...) {}
+    }
+}
+
+void CircuitRuntime::compile(const std::string &program) {
+  auto g = dynamic_cast<const GraphCapable *>(&factory);
+  if (!g) throw std::runtime_error("compile: this ciphertext factory cannot record circuits (no GraphCapable)");
+  if (graph) throw std::runtime_error("compile: a circuit has already been recorded by this runtime");
+  auto before = snapshot();
+  executeAst(program);  // eager warm-up
+  g->synchronize();
+  vars = std::move(before);
+  for (const auto &kv : vars)
+    if (kv.second.ctxt) graphInputs[kv.first] = kv.second.ctxt->clone();
+  g->graphBegin();
+  try {
+    executeAst(program);
+  } catch (...) {
+    g->graphAbort();
+    throw;
+  }
+  graph = g->graphEnd();
+  g->graphLaunch(graph);
+}
+
+void CircuitRuntime::replay() {
+  auto g = dynamic_cast<const GraphCapable *>(&factory);
+  if (!g || !graph) throw std::runtime_error("replay: no recorded circuit");
+  g->graphLaunch(graph);
+}
+
+void CircuitRuntime::setInput(const std::string &name, const std::vector<int64_t> &values) {
+  auto g = dynamic_cast<const GraphCapable *>(&factory);
+  auto it = graphInputs.find(name);
+  if (!g || it == graphInputs.end()) throw std::runtime_error("setInput: '" + name + "' is not an input of a recorded circuit");
+  g->rewriteCiphertext(*it->second, values);
+}
+void CircuitRuntime::setInputBatch(const std::string &name, const std::vector<std::vector<int64_t>> &perInstance) {
+  auto g = dynamic_cast<const GraphCapable *>(&factory);
+  auto it = graphInputs.find(name);
+  if (!g || it == graphInputs.end()) throw std::runtime_error("setInputBatch: '" + name + "' is not an input of a recorded circuit");
+  g->rewriteCiphertextBatch(*it->second, perInstance);
 }

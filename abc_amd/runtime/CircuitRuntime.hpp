@@ -35,6 +35,22 @@ class CircuitRuntime {
   OutputIdentifierValuePairs getOutput(const std::string &outputs);
   void printOutput(const std::string &outputs, std::ostream &target);
 
+  // ---- recorded circuits (needs a factory that implements GraphCapable, e.g. HipCiphertextFactory) ----
+  // compile: interpret `program` once eagerly (fills plaintext caches, sizes scratch), roll the variables back, interpret it
+  // again with the factory in recording mode, run the recording once.  Afterwards the variables hold the program's results,
+  // as after executeAst -- and replay() re-evaluates the SAME operation sequence on whatever the input ciphertexts contain
+  // now (setInput), without interpreting or dispatching anything on the host: one graph launch.
+  // Static circuits only: the recorded sequence is the one this interpretation took (public loops are unrolled into it).
+  // Value lifetimes need no analysis pass: a variable read is a copy-on-write reference (no device copy), an in-place
+  // operation on a value nobody else holds runs in place, and buffers that die inside the recording are reused inside it.
+  void compile(const std::string &program);
+  void replay();
+  bool compiled() const { return graph != nullptr; }
+  // new contents for an input declared in the constructor's input block (same buffer, same address)
+  void setInput(const std::string &name, const std::vector<int64_t> &values);
+  void setInputBatch(const std::string &name, const std::vector<std::vector<int64_t>> &perInstance);
+  ~CircuitRuntime();
+
   struct Token {
     enum Kind { End, Ident, Int, Punct } kind = End;
     std::string text;
@@ -51,6 +67,9 @@ class CircuitRuntime {
 
   AbstractCiphertextFactory &factory;
   std::map<std::string, Variable> vars;
+  void *graph = nullptr;
+  std::map<std::string, std::unique_ptr<AbstractCiphertext>> graphInputs;  // holds the recorded input buffers alive
+  std::map<std::string, Variable> snapshot() const;
   std::vector<Token> toks;
   size_t pos = 0;
 

@@ -297,3 +297,37 @@ std::string HipCiphertextFactory::getString(AbstractCiphertext &abstractCipherte
   ss << " ]";
   return ss.str();
 }
+
+// ---- GraphCapable ----
+void HipCiphertextFactory::graphBegin() const { abcHipCheck(abc_hip_graph_begin(ctx), "graph capture"); }
+void *HipCiphertextFactory::graphEnd() const {
+  void *g = nullptr;
+  abcHipCheck(abc_hip_graph_end(ctx, &g), "graph capture");
+  return g;
+}
+void HipCiphertextFactory::graphAbort() const {
+  void *g = nullptr;
+  if (abc_hip_graph_end(ctx, &g) == 0 && g) abc_hip_graph_destroy(ctx, g);
+}
+void HipCiphertextFactory::graphLaunch(void *graph) const { abcHipCheck(abc_hip_graph_launch(ctx, graph), "graph launch"); }
+void HipCiphertextFactory::graphDestroy(void *graph) const { abcHipCheck(abc_hip_graph_destroy(ctx, graph), "graph destroy"); }
+void HipCiphertextFactory::synchronize() const { abcHipCheck(abc_hip_sync(ctx), "synchronize"); }
+
+void HipCiphertextFactory::rewriteCiphertextBatch(AbstractCiphertext &target, const std::vector<std::vector<int64_t>> &perInstance) const {
+  if (ckksMode) queueBatchedRealInput([&] {
+    std::vector<std::vector<double>> rows;
+    for (const auto &r : perInstance) rows.emplace_back(r.begin(), r.end());
+    return rows;
+  }());
+  else queueBatchedInput(perInstance);
+  rewriteCiphertext(target, perInstance.at(0));
+}
+void HipCiphertextFactory::rewriteCiphertext(AbstractCiphertext &target, const std::vector<int64_t> &values) const {
+  auto &dst = dynamic_cast<HipCiphertext &>(target);
+  if (dst.level() != limbs) throw std::runtime_error("rewriteCiphertext: the target must be a fresh (top-level) ciphertext");
+  auto fresh = createCiphertext(values);  // serves a queued batch if there is one
+  // straight into the existing buffer, shared or not: every holder of this buffer is meant to see the new input
+  abcHipCheck(abc_hip_memcpy_d2d(ctx, const_cast<uint64_t *>(static_cast<const HipCiphertext &>(dst).devicePtr()),
+                                 dynamic_cast<const HipCiphertext &>(*fresh).devicePtr(), ciphertextWords() * 8),
+              "rewrite ciphertext");
+}

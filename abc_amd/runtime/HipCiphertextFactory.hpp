@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "CkksEncoder.hpp"
+#include "GraphCapable.hpp"
 #include "plugin_api.hpp"
 
 struct abc_hip_ctx;
@@ -29,7 +30,7 @@ struct HipSchemeConfig {
   size_t batch = 1;
 };
 
-class HipCiphertextFactory : public AbstractCiphertextFactory {
+class HipCiphertextFactory : public AbstractCiphertextFactory, public GraphCapable {
   const unsigned int ciphertextSlotSize = 16'384;
   abc_hip_ctx *ctx = nullptr;  // owned: device tables + keys
   int limbs = 0;               // data limbs L
@@ -118,6 +119,16 @@ class HipCiphertextFactory : public AbstractCiphertextFactory {
   std::unique_ptr<AbstractCiphertext> createCiphertext(std::unique_ptr<AbstractValue> &&abstractValue) const override;
   void decryptCiphertext(AbstractCiphertext &abstractCiphertext, std::vector<int64_t> &ciphertextData) const override;
   std::string getString(AbstractCiphertext &abstractCiphertext) const override;
+
+  // GraphCapable: recorded circuits (abc_hip_graph_*)
+  void graphBegin() const override;
+  void *graphEnd() const override;
+  void graphAbort() const override;
+  void graphLaunch(void *graph) const override;
+  void graphDestroy(void *graph) const override;
+  void synchronize() const override;
+  void rewriteCiphertext(AbstractCiphertext &target, const std::vector<int64_t> &values) const override;
+  void rewriteCiphertextBatch(AbstractCiphertext &target, const std::vector<std::vector<int64_t>> &perInstance) const override;
 };
 
 // maps a non-zero C-ABI status to the reference's error convention (std::runtime_error)

@@ -148,7 +148,12 @@ int abc_hip_mod_switch(abc_hip_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, 
  * eager per-call dispatch of SpecialRuntimeVisitor, src/runtime/RuntimeVisitor.cpp:40-159).
  * Everything enqueued on the context between begin and end is recorded instead of executed; the sequence must have
  * run once eagerly before (so that no scratch allocation happens while capturing) and may only use device pointers
- * that stay valid for every launch.  abc_hip_encrypt / abc_hip_keygen / *_h2d / *_d2h are not capturable. */
+ * that stay valid for every launch.  abc_hip_encrypt / abc_hip_keygen / *_h2d / *_d2h are not capturable.
+ * Buffers: abc_hip_malloc inside a capture is served from the cache only (never the driver), and every buffer the recorded
+ * sequence touched is pinned to the graph until abc_hip_graph_destroy -- freeing one earlier parks it instead of recycling
+ * it, so a replay can never run over memory that has been handed to someone else.  A buffer that existed before the capture
+ * and is freed inside it is an INPUT of the circuit: it keeps its address and contents are the caller's to refresh before a
+ * replay (HipCiphertextFactory::rewriteCiphertext). */
 int abc_hip_graph_begin(abc_hip_ctx *ctx);
 int abc_hip_graph_end(abc_hip_ctx *ctx, void **graph_exec_out);
 int abc_hip_graph_launch(abc_hip_ctx *ctx, void *graph_exec);

@@ -188,5 +188,60 @@ int main() {
     EXPECT_TRUE(first == got[0]);
     EXPECT_THROWS(fb.queueBatchedInput(std::vector<std::vector<int64_t>>(B + 1, std::vector<int64_t>{1})));
   });
+  t.run("recorded circuit: compile once, replay on new inputs, same results as the eager interpreter", [&] {
+    const std::string inputs = "secret int a = {3, 3, 1, 4, 5, 9}; secret int b = {0, 1, 2, 1, 10, 21}; int k = {2, 2, 2, 2, 2, 2};";
+    const std::string program =
+        "secret int r = a *** b;\n"
+        "r = r +++ rotate(r, 1);\n"
+        "for (int i = 0; i < 2; i = i + 1) { r = r +++ a; }\n"  // a public loop: unrolled into the recording
+        "r = r --- (b *** k);\n"
+        "a = a +++ b;\n";  // an input that is overwritten: the recording must keep reading the original buffer
+    auto expect = [&](const std::vector<int64_t> &va, const std::vector<int64_t> &vb) {
+      // padded semantics: slot i beyond the data holds the last value
+      auto at = [](const std::vector<int64_t> &v, size_t i) { return i < v.size() ? v[i] : v.back(); };
+      std::vector<int64_t> r(8);
+      for (size_t i = 0; i < 8; ++i) {
+        const int64_t m0 = at(va, i) * at(vb, i), m1 = at(va, i + 1) * at(vb, i + 1);
+        r[i] = m0 + m1 + 2 * at(va, i) - 2 * at(vb, i);
+      }
+      return r;
+    };
+    CircuitRuntime rt(f, inputs);
+    rt.compile(program);
+    EXPECT_TRUE(rt.compiled());
+    {
+      auto out = rt.getOutput("y = r; z = a;");
+      expectPrefix(outputOf(f, out, "y"), expect(d1, d2));
+      expectPrefix(outputOf(f, out, "z"), {3, 4, 3, 5, 15, 30});
+    }
+    const std::vector<int64_t> a2 = {7, 1, 0, 2, 9, 4}, b2 = {5, 5, 1, 3, 2, 6};
+    rt.setInput("a", a2);
+    rt.setInput("b", b2);
+    rt.replay();
+    {
+      auto out = rt.getOutput("y = r; z = a;");
+      expectPrefix(outputOf(f, out, "y"), expect(a2, b2));
+      expectPrefix(outputOf(f, out, "z"), {12, 6, 1, 5, 11, 10});
+    }
+    rt.replay();  // replays are idempotent: inputs are never written by the recording
+    {
+      auto out = rt.getOutput("y = r;");
+      expectPrefix(outputOf(f, out, "y"), expect(a2, b2));
+    }
+    // other work on the same factory between replays must not disturb the recording's buffers
+    auto other = f.createCiphertext(d1);
+    for (int i = 0; i < 4; ++i) other = other->multiply(*other->rotateRows(1));
+    rt.setInput("a", d1);
+    rt.setInput("b", d2);
+    rt.replay();
+    {
+      auto out = rt.getOutput("y = r;");
+      expectPrefix(outputOf(f, out, "y"), expect(d1, d2));
+    }
+    // a program that encrypts inside cannot be recorded: clean error, the factory stays usable
+    CircuitRuntime bad(f, "secret int a = {1, 2};");
+    EXPECT_THROWS(bad.compile("secret int t = {4, 5}; a = a +++ t;"));
+    checkPadded(f, *f.createCiphertext(d1)->add(*f.createCiphertext(d2)), {3, 4, 3, 5, 15, 30});
+  });
   return t.summary();
 }
