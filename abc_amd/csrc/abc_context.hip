@@ -443,6 +443,13 @@ using namespace abc;
     if (hipSetDevice((c)->device) != hipSuccess) { set_error("hipSetDevice failed"); return 1; } \
   } while (0)
 
+// Host-synchronising entry points cannot be recorded, and letting HIP find that out invalidates the capture for good on this
+// runtime (the stream keeps returning hipErrorStreamCaptureInvalidated even after hipStreamEndCapture): refuse up front.
+#define NOT_CAPTURABLE(c, what)                                                                                   \
+  do {                                                                                                            \
+    if ((c)->capture_active) { set_error(what ": not capturable (host transfer / synchronisation inside abc_hip_graph_begin..end)"); return 1; } \
+  } while (0)
+
 extern "C" {
 
 const char *abc_hip_last_error(void) { return g_err.c_str(); }
@@ -626,12 +633,14 @@ int abc_hip_ctx_info(const abc_hip_ctx *c, int what) {
 
 int abc_hip_set_stream(abc_hip_ctx *c, void *stream) {
   CTX_GUARD(c);
+  NOT_CAPTURABLE(c, "abc_hip_set_stream");
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   c->stream = stream ? (hipStream_t)stream : c->own_stream;  // NULL selects the context's private stream again
   return 0;
 }
 int abc_hip_sync(abc_hip_ctx *c) {
   CTX_GUARD(c);
+  NOT_CAPTURABLE(c, "abc_hip_sync");
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -720,12 +729,14 @@ int abc_hip_free(abc_hip_ctx *c, void *d_ptr) {
     // cap reached: exact-size buckets strand blocks when sizes vary, so give the whole cache back, not just this block
     if (over_cap && trim_cache(c)) return 1;
   }
+  NOT_CAPTURABLE(c, "abc_hip_free of an uncached buffer");
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   ABC_HIP_CHECK(hipFree(d_ptr));
   return 0;
 }
 int abc_hip_trim(abc_hip_ctx *c) {
   CTX_GUARD(c);
+  NOT_CAPTURABLE(c, "abc_hip_trim");
   return trim_cache(c);
 }
 size_t abc_hip_cached_bytes(abc_hip_ctx *c) {
@@ -735,18 +746,21 @@ size_t abc_hip_cached_bytes(abc_hip_ctx *c) {
 }
 int abc_hip_ctx_reload_env(abc_hip_ctx *c) {
   CTX_GUARD(c);
+  NOT_CAPTURABLE(c, "abc_hip_ctx_reload_env");
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   read_switches(c);
   return 0;
 }
 int abc_hip_memcpy_h2d(abc_hip_ctx *c, void *d, const void *h, size_t bytes) {
   CTX_GUARD(c);
+  NOT_CAPTURABLE(c, "abc_hip_memcpy_h2d");
   ABC_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   return 0;
 }
 int abc_hip_memcpy_d2h(abc_hip_ctx *c, void *h, const void *d, size_t bytes) {
   CTX_GUARD(c);
+  NOT_CAPTURABLE(c, "abc_hip_memcpy_d2h");
   ABC_HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   return 0;
@@ -760,6 +774,7 @@ int abc_hip_memcpy_d2d(abc_hip_ctx *c, void *dst, const void *src, size_t bytes)
 // ---- keys ----
 int abc_hip_keygen(abc_hip_ctx *c, uint64_t seed) {
   CTX_GUARD(c);
+  NOT_CAPTURABLE(c, "abc_hip_keygen");
   try {
     return keygen(c, seed);
   } catch (const std::exception &e) {
@@ -769,6 +784,7 @@ int abc_hip_keygen(abc_hip_ctx *c, uint64_t seed) {
 }
 int abc_hip_keygen_secure(abc_hip_ctx *c) {
   CTX_GUARD(c);
+  NOT_CAPTURABLE(c, "abc_hip_keygen_secure");
   try {
     return keygen_secure(c);
   } catch (const std::exception &e) {
@@ -777,6 +793,7 @@ int abc_hip_keygen_secure(abc_hip_ctx *c) {
   }
 }
 static int load_key(abc_hip_ctx *c, uint64_t **slot, const uint64_t *h, size_t words) {
+  NOT_CAPTURABLE(c, "key upload");
   if (!*slot) ABC_HIP_CHECK(hipMalloc(slot, words * 8));
   ABC_HIP_CHECK(hipMemcpy(*slot, h, words * 8, hipMemcpyHostToDevice));
   return 0;
@@ -795,6 +812,7 @@ int abc_hip_load_galois_key(abc_hip_ctx *c, uint32_t elt, const uint64_t *h) {
   return 0;
 }
 static int get_key(abc_hip_ctx *c, const uint64_t *d, uint64_t *h, size_t words, const char *what) {
+  NOT_CAPTURABLE(c, "key download");
   if (!d) { set_error(std::string("key not present: ") + what); return 1; }
   ABC_HIP_CHECK(hipStreamSynchronize(c->stream));
   ABC_HIP_CHECK(hipMemcpy(h, d, words * 8, hipMemcpyDeviceToHost));
@@ -818,8 +836,8 @@ uint32_t abc_hip_galois_elt_from_step(abc_hip_ctx *c, int step) { return c ? elt
 // ---- encode / encrypt / decrypt ----
 int abc_hip_batch_encode(abc_hip_ctx *c, const int64_t *v, uint64_t *p, size_t count) { CTX_GUARD(c); return batch_encode(c, v, p, count); }
 int abc_hip_batch_decode(abc_hip_ctx *c, const uint64_t *p, int64_t *v, size_t count) { CTX_GUARD(c); return batch_decode(c, p, v, count); }
-int abc_hip_encrypt(abc_hip_ctx *c, const uint64_t *p, uint64_t seed, uint64_t *ct, size_t count) { CTX_GUARD(c); return encrypt(c, p, seed, ct, count); }
-int abc_hip_encrypt_secure(abc_hip_ctx *c, const uint64_t *p, uint64_t *ct, size_t count) { CTX_GUARD(c); return encrypt_secure(c, p, ct, count); }
+int abc_hip_encrypt(abc_hip_ctx *c, const uint64_t *p, uint64_t seed, uint64_t *ct, size_t count) { CTX_GUARD(c); NOT_CAPTURABLE(c, "abc_hip_encrypt"); return encrypt(c, p, seed, ct, count); }
+int abc_hip_encrypt_secure(abc_hip_ctx *c, const uint64_t *p, uint64_t *ct, size_t count) { CTX_GUARD(c); NOT_CAPTURABLE(c, "abc_hip_encrypt_secure"); return encrypt_secure(c, p, ct, count); }
 int abc_hip_decrypt(abc_hip_ctx *c, const uint64_t *ct, int size, int nl, uint64_t *p, size_t count) {
   CTX_GUARD(c);
   if (nl < 1 || nl > c->L) { set_error("decrypt: bad limb count"); return 1; }

@@ -445,6 +445,10 @@ void CircuitRuntime::compile(const std::string &program) {
   g->graphBegin();
   try {
     executeAst(program);
+  } catch (const std::exception &e) {
+    g->graphAbort();
+    throw std::runtime_error(std::string("while recording the circuit (only device work can be recorded; encryption, i.e. a "
+                                         "secret declaration with a public initialiser, cannot): ") + e.what());
   } catch (...) {
     g->graphAbort();
     throw;
