@@ -1198,7 +1198,7 @@ struct PairOps {
 };
 
 template <int MODE, bool GAL, int NL>
-__global__ __launch_bounds__(512, 2) void k_split4_main_fp(DevCtx c, const double *__restrict__ part,
+__global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const double *__restrict__ part,
                                                                    const double *__restrict__ tpart, const u64 *__restrict__ opa,
                                                                    const u64 *__restrict__ opb, size_t opa_stride, size_t opb_stride,
                                                                    int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out, u32 gelt) {
@@ -1428,6 +1428,13 @@ static bool launch_split4_special(hipStream_t st, abc_hip_ctx *c, size_t cc, int
   }
   return true;
 }
+
+
+// (A persistent form of k_split4_main_fp -- one workgroup per (prime, block) looping over ciphertexts, key words kept in
+// registers, the next ciphertext's operands requested before the current one is transformed -- was built and measured this
+// round: 351 k mul+relin/s with explicit prefetch at one workgroup per CU (217 VGPRs), 301 k/s at two per CU (128 VGPRs, 18
+// spilled), against 380 k/s for the per-item grid below: the hardware's workgroup turnover hides more than eight resident
+// wavefronts with a hand-rolled pipeline do.  Removed again)
 
 // K2a..K2c on one chunk (the half-done decomposition limbs are in s.dec)
 template <int MODE, bool GAL>
