@@ -1231,9 +1231,13 @@ __global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const doubl
   const double *__restrict__ src = (Wc < nl - 1) ? part + ((ct * (nl + 1) + I) * nl + (Wc < I ? Wc : Wc + 1)) * (size_t)c.ps + base
                                                  : tpart + ((ct * 2 + (Wc - (nl - 1))) * nl + I) * (size_t)c.ps + base;
   double xin[16];
-  if (has_limb) {
+  if (has_limb) {  // eight 16-byte loads: slot g*8 + k = element k*128 + 2*lane + g (ntt_fwd_tail1024_pairs)
 #pragma unroll
-    for (int k = 0; k < 16; k++) xin[k] = src[(k << 6) + lane];  // PassIdx<10, 0, 4>: slot k = element (k << 6) + lane
+    for (int k = 0; k < 8; k++) {
+      const f64x2 v = *reinterpret_cast<const f64x2 *>(src + (k << 7) + 2 * lane);
+      xin[k] = v.x;
+      xin[8 + k] = v.y;
+    }
   }
   auto load_pair = [&](int e, PairOps<MODE, NL> &o) {
 #pragma unroll
@@ -1267,9 +1271,9 @@ __global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const doubl
   __syncthreads();
   if (has_limb) {
     double *buf = dyn + W * lds_words(10);
-    auto ld = [&](int r, int) { return fp_centre(xin[r], q, qinv); };
-    auto st = [&](int, int i, double v) { buf[lds_pad(i)] = v; };
-    ntt_fwd_block_a<10, FpArith, decltype(ld), decltype(st), true>(buf, ld, st, t, m, 4, blk, lane, ltw);
+#pragma unroll
+    for (int r = 0; r < 16; r++) xin[r] = fp_centre(xin[r], q, qinv);
+    ntt_fwd_tail1024_pairs<FpArith>(buf, xin, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk, lane, ltw);
   }
   __syncthreads();
   const double *tt0 = dyn + (nl - 1) * lds_words(10), *tt1 = dyn + nl * lds_words(10);
@@ -1544,7 +1548,7 @@ static ChunkPlan plan_chunks(const abc_hip_ctx *c, int nl, size_t count) {
     const size_t per_ct_bytes = fused_scratch_limbs(nl) * c->n * 8;
     const size_t cap = ((size_t)4 << 30) / per_ct_bytes / (size_t)p.lanes;  // scratch capped at 4 GiB
     p.chunk = (count + p.lanes - 1) / p.lanes;
-    if (p.chunk > 256) p.chunk = 256;
+    if (p.chunk > 128) p.chunk = 128;  // measured this round: 128 > 256 > 64 > 512 (+2 / 0 / -0.5 / -1.5 %)
     if (p.chunk > cap) p.chunk = cap;
     if (p.chunk < 1) p.chunk = 1;
   }

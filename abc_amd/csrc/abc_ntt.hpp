@@ -436,6 +436,54 @@ __device__ __forceinline__ void ntt_fwd_block_a(typename A::E *lds, Load load, S
   }
 }
 
+
+// ---- 1024-point forward block, one wavefront, 16-byte operand loads ----------------------------------------------------------
+// Schedule 3 + 4 + 3 instead of 4 + 4 + 2: the first pass is two radix-8 groups on ADJACENT positions (lane l owns positions
+// 2l and 2l + 1 of every 128-element row), so the caller fetches its sixteen operands as eight 16-byte loads, lane stride 16
+// bytes -- fully coalesced -- where the 4 + 4 + 2 schedule needs sixteen 8-byte loads.  Same number of LDS exchanges (two).
+//   xin slot g*8 + k  =  block element k*128 + 2*lane + g      (g = 0, 1;  k = 0..7)
+// Per-lane twiddles (passes B and C) come from the LDS table `ltw` (block_twiddles_fetch/store); pass A's are wave-uniform.
+template <class A, class Store>
+__device__ __forceinline__ void ntt_fwd_tail1024_pairs(typename A::E *lds, typename A::E (&x)[16], Store store,
+                                                       const typename A::Table &t, const Mod &m, int S0, int b, int lane,
+                                                       const typename A::TW *ltw) {
+  constexpr int LB = 10;
+  const typename A::K kk = A::consts(m);
+  {  // pass A: stages 0..2
+    const int hi[2] = {0, 0};
+    fwd_pass<A, LB, 0, 3>(x, hi, t, kk, S0, b);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      typename A::E *p = lds + lds_pad((k << 7) + 2 * lane);  // two adjacent words (an even index never straddles a pad)
+      p[0] = x[k];
+      p[1] = x[8 + k];
+    }
+  }
+  wave_sync();
+  {  // pass B: stages 3..6
+    using P = PassIdx<LB, 3, 4>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(lane, hi, lo);
+    lds_load<LB, 3, 4>(lds, x, hi, lo);
+    A::template fwd_begin<1>(x, kk);
+    fwd_pass_lds<A, LB, 3, 4>(x, hi, ltw, kk);
+    lds_store<LB, 3, 4>(lds, x, hi, lo);
+  }
+  wave_sync();
+  {  // pass C: stages 7..9
+    using P = PassIdx<LB, 7, 3>;
+    int hi[P::NG], lo[P::NG];
+    P::groups(lane, hi, lo);
+    lds_load<LB, 7, 3>(lds, x, hi, lo);
+    A::template fwd_begin<2>(x, kk);
+    fwd_pass_lds<A, LB, 7, 3>(x, hi, ltw, kk);
+#pragma unroll
+    for (int g = 0; g < P::NG; g++)
+#pragma unroll
+      for (int k = 0; k < 8; k++) store(g * 8 + k, P::elem(hi[g], lo[g], k), x[g * 8 + k]);
+  }
+}
+
 template <int LB, bool GUARD = true, class Load, class Store>
 __device__ __forceinline__ void ntt_fwd_block(u64 *lds, Load load, Store store, const NttTable &t, const Mod &m, int S0,
                                               int b) {
