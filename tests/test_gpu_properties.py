@@ -105,3 +105,58 @@ def test_ckks_roundtrip_and_homomorphisms(capi, n, bits):
     assert np.abs(dec(m, scale * scale / primes[L - 1]) - x * y).max() < 1e-5
     assert np.abs(dec(g.rotate(g.rotate(cx, 3), -3), scale) - x).max() < 1e-4
     assert np.abs(dec(g.rotate(cx, 1), scale) - np.roll(x, -1)).max() < 1e-4
+
+
+# ---- noise-sensitive decrypted-level checks (no oracle involved: the expected values are plain integer arithmetic mod t) ----
+def _centre(v, t):
+    v = np.mod(v, t)
+    return np.where(v > t // 2, v - t, v)
+
+
+@pytest.mark.parametrize("n,depth", [(8192, 3), (16384, 7)])
+def test_bfv_multiplication_chain_near_budget_exhaustion(capi, n, depth):
+    """BFVDefault(8192) carries a depth-3 chain of ct x ct products with 20-bit plaintexts, BFVDefault(16384) depth 7 (one
+    short of exhausting the noise budget: the next product decrypts to garbage).  A mistake in the BEHZ rounding, the
+    mod-down rounding or the relinearisation that only shifts the noise by a few bits shows up here and nowhere else."""
+    g = _bfv(capi, n)
+    t = g.t
+    rng = np.random.default_rng(depth)
+    x = rng.integers(-(t // 2), t // 2, size=(depth + 1, n))
+    cts = [_enc(g, x[i], 10 + i) for i in range(depth + 1)]
+    acc, want = cts[0], x[0].astype(object)
+    for i in range(1, depth + 1):
+        acc = g.mul_relin(acc, cts[i])
+        want = want * x[i].astype(object)
+        assert np.array_equal(_dec(g, acc)[0], _centre(want, t).astype(np.int64)), "chain broke at depth %d" % i
+
+
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_bfv_multiply_plain_large_and_negative_constants(capi, n):
+    g = _bfv(capi, n)
+    t = g.t
+    rng = np.random.default_rng(n + 1)
+    a = rng.integers(-(t // 2), t // 2, size=(1, n))
+    ca = _enc(g, a, 3)
+    for const in (t // 2, -(t // 2), -1, 1, 2, -(t // 3), 786431):
+        p = np.full((1, n), const, dtype=np.int64)
+        got = _dec(g, g.multiply_plain(ca, g.batch_encode(p)))
+        assert np.array_equal(got, _centre(a.astype(object) * const, t).astype(np.int64)), const
+    # slot-wise random multipliers over the whole plaintext range, then add / subtract a plain vector of the same kind
+    m = rng.integers(-(t // 2), t // 2, size=(1, n))
+    got = _dec(g, g.sub_plain(g.add_plain(g.multiply_plain(ca, g.batch_encode(m)), g.batch_encode(m)), g.batch_encode(a)))
+    assert np.array_equal(got, _centre(a.astype(object) * m + m - a, t).astype(np.int64))
+
+
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_bfv_naf_rotations_compose(capi, n):
+    """step counts without a Galois key of their own go through the non-adjacent form (Evaluator::rotate_internal): every
+    composite rotation must equal the cyclic shift of each row, for positive, negative and near-half-row steps"""
+    g = _bfv(capi, n)
+    rng = np.random.default_rng(7)
+    a = rng.integers(-1000, 1000, size=(1, n))
+    ca = _enc(g, a, 5)
+    row = n // 2
+    rows = a.reshape(2, row)
+    for steps in (3, -3, 7, 11, -13, 100, row - 1, -(row - 1), 1365, -2047):
+        got = _dec(g, g.rotate(ca, steps)).reshape(2, row)
+        assert np.array_equal(got, np.roll(rows, -steps, axis=1)), steps
