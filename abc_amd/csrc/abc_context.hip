@@ -30,6 +30,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_split2 = env_on("ABC_HIP_NO_SPLIT2");
   s.no_split3 = env_on("ABC_HIP_NO_SPLIT3");
   s.no_split4 = env_on("ABC_HIP_NO_SPLIT4");
+  s.no_isplit = env_on("ABC_HIP_NO_ISPLIT");
   s.split4_special = env_on("ABC_HIP_SPLIT4_SPECIAL");
   s.no_tensor_decomp = env_on("ABC_HIP_NO_TENSOR_DECOMP");
   s.no_tensor_intt = env_on("ABC_HIP_NO_TENSOR_INTT");
@@ -209,6 +210,7 @@ static int build_context(abc_hip_ctx *c) {
     k.inv_special[j] = invmod(qsp % q, q);
     k.inv_special_s[j] = shoup(k.inv_special[j], q);
     k.special_mod_q[j] = qsp % q;
+    k.special_mod_q_s[j] = shoup(k.special_mod_q[j], q);
     k.inv_special_c[j] = k.inv_special[j] > q / 2 ? -(double)(q - k.inv_special[j]) : (double)k.inv_special[j];
     k.inv_special_cq[j] = k.inv_special_c[j] / (double)q;
     k.special_c[j] = k.special_mod_q[j] > q / 2 ? -(double)(q - k.special_mod_q[j]) : (double)k.special_mod_q[j];

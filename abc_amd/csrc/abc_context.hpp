@@ -26,7 +26,7 @@ struct DevConst {
   // key switching / modulus switching
   u64 inv_special[kMaxLimbs], inv_special_s[kMaxLimbs];        // q_special^-1 mod q_j (+Shoup)
   u64 inv_qlast[kMaxLimbs][kMaxLimbs], inv_qlast_s[kMaxLimbs][kMaxLimbs];  // [l][j] = q_l^-1 mod q_j
-  u64 special_mod_q[kMaxLimbs];
+  u64 special_mod_q[kMaxLimbs], special_mod_q_s[kMaxLimbs];
   double inv_special_c[kMaxLimbs], inv_special_cq[kMaxLimbs];  // fp64 path: centred value and value / q_j
   double special_c[kMaxLimbs], special_cq[kMaxLimbs];          // q_special mod q_j, centred, and that / q_j
   double inv_qlast_c[kMaxLimbs][kMaxLimbs], inv_qlast_cq[kMaxLimbs][kMaxLimbs];  // same for inv_qlast (rescale)                                // q_special mod q_j (key generation)
@@ -140,7 +140,7 @@ struct abc_hip_ctx {
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
   struct Switches {
-    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
+    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_isplit = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
     bool tailmac_serial = false, no_galois_fusion = false;
     size_t chunk = 0, few_limbs = 48;
     int lanes = 2;
@@ -219,5 +219,10 @@ int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *ou
 int keyswitch_fused(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out2, int nl, size_t count,
                     const u64 *addend, size_t addend_stride, bool add_c1);
 int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count);
+// integer twins of the split kernels (abc_kernels_isplit.hip)
+bool isplit_applies(const abc_hip_ctx *c, int nl);
+size_t isplit_scratch_words(const abc_hip_ctx *c, int nl);
+int isplit_chunk(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb,
+                 size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt);
 
 }  // namespace abc

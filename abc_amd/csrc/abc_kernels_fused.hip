@@ -1601,10 +1601,37 @@ struct LaneScope {
   }
 };
 
+static int run_isplit(abc_hip_ctx *c, int mode, const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, bool add_c1,
+                      const u64 *key, u64 *out, int nl, size_t count, u32 gelt) {
+  const size_t N = (size_t)c->n;
+  const ChunkPlan p = plan_chunks(c, nl, count);
+  const size_t per_ct = isplit_scratch_words(c, nl);
+  if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
+  LaneScope scope(c, p.lanes);
+  if (scope.fork()) return 1;
+  int turn = 0;
+  for (size_t off = 0; off < count; off += p.chunk, turn++) {
+    const size_t cc = (count - off < p.chunk) ? count - off : p.chunk;
+    const int l = (p.lanes > 1) ? turn % p.lanes : 0;
+    hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
+    u64 *scratch = (u64 *)c->ws + (size_t)l * p.chunk * per_ct;
+    if (isplit_chunk(c, st, scratch, cc, nl, mode, opa + off * opa_stride, opb ? opb + off * opb_stride : nullptr, opa_stride, opb_stride,
+                     add_c1 ? 1 : 0, key, out + off * 2 * (size_t)nl * N, gelt))
+      return 1;
+  }
+  return scope.join();
+}
+
 // ---- CKKS multiply + relinearise ----
+// integer split sequence (abc_kernels_isplit.hip): chains with a prime above 2^50
+static int run_isplit(abc_hip_ctx *c, int mode, const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, bool add_c1,
+                      const u64 *key, u64 *out, int nl, size_t count, u32 gelt);
+
 template <int LB>
 static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count) {
   const size_t N = (size_t)1 << LB;
+  if (LB == 14 && !all_fp(c) && isplit_applies(c, nl))
+    return run_isplit(c, 0, a, b, 2 * (size_t)nl * N, 2 * (size_t)nl * N, false, c->d_relin, out, nl, count, 0u);
   const ChunkPlan p = plan_chunks(c, nl, count);
   // scratch limbs of the split2+ kernels are c->dc.ps words apart (N plus an optional pad, see abc_hip_ctx_create)
   const bool use2 = LB == 14 && all_fp(c) && !c->sw.no_tensor_decomp && !c->sw.no_split && !c->sw.no_split2 && nl <= 12;
@@ -1682,6 +1709,8 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
                          const u64 *addend, size_t addend_stride, bool add_c1, u32 gelt = 0) {
   const size_t N = (size_t)1 << LB;
   const bool ckks = (c->scheme == 2);
+  if (LB == 14 && ckks && !all_fp(c) && isplit_applies(c, nl))
+    return run_isplit(c, 1, target, addend, target_stride, addend_stride, add_c1, key, out, nl, count, gelt);
   const ChunkPlan p = plan_chunks(c, nl, count);
   const bool use2 = LB == 14 && ckks && all_fp(c) && !c->sw.no_split && !c->sw.no_split2 && nl <= 12;
   const size_t SN = use2 ? (size_t)c->dc.ps : N;
@@ -1756,7 +1785,8 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
 // CKKS rotation with the Galois permutation folded into the key switch (N = 2^14, fp64 split path): in [count][2][nl][N]
 // NTT form; out = (g(c0) + ks0, ks1), ks = KeySwitch(g(c1)).  -1: not applicable, caller permutes first.
 int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *out, int nl, size_t count) {
-  if (c->logn != 14 || c->scheme != 2 || !all_fp(c) || in == out) return -1;
+  if (c->logn != 14 || c->scheme != 2 || in == out) return -1;
+  if (!all_fp(c) && !isplit_applies(c, nl)) return -1;
   if (c->sw.no_split || c->sw.no_fused || c->sw.no_galois_fusion) return -1;
   if (!count) return 0;
   const size_t N = (size_t)c->n, pw = (size_t)nl * N;

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = {
     "default": {},
-    "integer_transforms": {"ABC_HIP_NO_FP64": "1"},
+    "integer_transforms": {"ABC_HIP_NO_FP64": "1"},  # integer split kernels (abc_kernels_isplit.hip), unguarded
+    "integer_v1": {"ABC_HIP_NO_FP64": "1", "ABC_HIP_NO_ISPLIT": "1"},  # round-1 integer sequence (LDS-resident transforms)
     "fp64_unsplit": {"ABC_HIP_NO_SPLIT": "1"},
     "fp64_separate_kernels": {"ABC_HIP_NO_SPLIT": "1", "ABC_HIP_NO_TENSOR_DECOMP": "1"},
     "fp64_split_v1": {"ABC_HIP_NO_SPLIT2": "1"},  # round-1 kernels: four launches, LDS-atomic accumulators
@@ -91,7 +92,7 @@ def test_ckks14_paths_bit_exact(variant, oracle14, capi, monkeypatch):
     g.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "integer_transforms", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
+@pytest.mark.parametrize("variant", ["default", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
 def test_ckks14_every_level_bit_exact(variant, oracle14, capi, monkeypatch):
     """multiply + relinearise and rotate at data levels 4, 3, 2 and 1 (the cooperative tail kernel runs nl wavefronts)"""
     o, primes, ins, want = oracle14
@@ -185,8 +186,11 @@ WIDE_CHAINS = {
 }
 
 
+@pytest.mark.parametrize("isplit", [True, False])
 @pytest.mark.parametrize("chain", list(WIDE_CHAINS))
-def test_ckks14_wide_prime_chains_every_level(chain, oracle_mod, capi):
+def test_ckks14_wide_prime_chains_every_level(chain, isplit, oracle_mod, capi, monkeypatch):
+    if not isplit:
+        monkeypatch.setenv("ABC_HIP_NO_ISPLIT", "1")  # the round-1 integer kernels stay selectable and tested
     n = 16384
     primes = oracle_mod.create_primes(n, WIDE_CHAINS[chain])
     o = oracle_mod.Oracle(oracle_mod.CKKS, n, primes)
@@ -215,7 +219,7 @@ def test_ckks14_wide_prime_chains_every_level(chain, oracle_mod, capi):
 # several chunks per lane: the hot call splits a batch into chunks that alternate over internal streams and reuse
 # per-lane scratch; every pair of a batch that spans chunk boundaries is checked, also with `out` aliasing `a`
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["default", "integer_transforms", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
+@pytest.mark.parametrize("variant", ["default", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
 def test_multi_chunk_batches_every_pair(variant, oracle14, capi, monkeypatch):
     import ctypes as C
     o, primes, ins, want = oracle14
