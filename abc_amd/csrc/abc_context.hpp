@@ -140,7 +140,7 @@ struct abc_hip_ctx {
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
   struct Switches {
-    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_isplit = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
+    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
     bool tailmac_serial = false, no_galois_fusion = false;
     size_t chunk = 0, few_limbs = 48;
     int lanes = 2;
@@ -219,6 +219,13 @@ int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *ou
 int keyswitch_fused(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out2, int nl, size_t count,
                     const u64 *addend, size_t addend_stride, bool add_c1);
 int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count);
+// split key switch without LDS-resident limbs (abc_kernels_gsplit.hip): N = 2^15, and the first step at N = 2^14 for small batches
+bool gsplit_applies(const abc_hip_ctx *c, int nl);
+size_t gsplit_scratch_words(const abc_hip_ctx *c, int nl);
+int gsplit_chunk15(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb,
+                   size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt);
+void gsplit_front14(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb, size_t opa_stride,
+                    double *hinv, double *part, u32 gelt);
 // integer twins of the split kernels (abc_kernels_isplit.hip)
 bool isplit_applies(const abc_hip_ctx *c, int nl);
 size_t isplit_scratch_words(const abc_hip_ctx *c, int nl);

@@ -1622,6 +1622,28 @@ static int run_isplit(abc_hip_ctx *c, int mode, const u64 *opa, const u64 *opb, 
   return scope.join();
 }
 
+// N = 2^15 (abc_kernels_gsplit.hip)
+static int run_gsplit15(abc_hip_ctx *c, int mode, const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, bool add_c1,
+                        const u64 *key, u64 *out, int nl, size_t count, u32 gelt) {
+  const size_t N = (size_t)c->n;
+  ChunkPlan p = plan_chunks(c, nl, count);
+  const size_t per_ct = gsplit_scratch_words(c, nl);
+  if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
+  LaneScope scope(c, p.lanes);
+  if (scope.fork()) return 1;
+  int turn = 0;
+  for (size_t off = 0; off < count; off += p.chunk, turn++) {
+    const size_t cc = (count - off < p.chunk) ? count - off : p.chunk;
+    const int l = (p.lanes > 1) ? turn % p.lanes : 0;
+    hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
+    u64 *scratch = (u64 *)c->ws + (size_t)l * p.chunk * per_ct;
+    if (gsplit_chunk15(c, st, scratch, cc, nl, mode, opa + off * opa_stride, opb ? opb + off * opb_stride : nullptr, opa_stride,
+                       opb_stride, add_c1 ? 1 : 0, key, out + off * 2 * (size_t)nl * N, gelt))
+      return 1;
+  }
+  return scope.join();
+}
+
 // ---- CKKS multiply + relinearise ----
 // integer split sequence (abc_kernels_isplit.hip): chains with a prime above 2^50
 static int run_isplit(abc_hip_ctx *c, int mode, const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, bool add_c1,
@@ -1652,8 +1674,14 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
     if constexpr (LB == 14) split = fuse_decomp && !c->sw.no_split;
     if constexpr (LB == 14) {
       if (split && !c->sw.no_split2 && nl <= 12) {  // second-generation split kernels: three launches, 84 limb transfers
-        hipLaunchKernelGGL(k_split2_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
-                           b + off * ctw, (double *)s.dec, nl);
+        // few ciphertexts in flight: the 139 KiB workgroups of the tensor kernel would leave most CUs idle for its whole
+        // duration; the block-wise inverse tails + register cross pass of abc_kernels_gsplit.hip spread over the chip instead
+        const bool lean = !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= 192;
+        if (lean)
+          gsplit_front14(st, c, cc, nl, 0, a + off * ctw, b + off * ctw, 0, (double *)s.coef, (double *)s.dec, 0u);
+        else
+          hipLaunchKernelGGL(k_split2_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
+                             b + off * ctw, (double *)s.dec, nl);
         if (!c->sw.no_split3) {
           launch_split3<0, false>(st, c, s, cc, nl, a + off * ctw, b + off * ctw, 0, 0, 0, c->d_relin, out + off * ctw, 0u);
           ABC_HIP_CHECK(hipGetLastError());
@@ -1689,6 +1717,11 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
 
 // -1: not applicable (ring too large for an LDS-resident limb) -> caller takes the generic path
 int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t count) {
+  if (c->logn == 15 && gsplit_applies(c, nl)) {
+    if (!count) return 0;
+    const size_t ctw = 2 * (size_t)nl * c->n;
+    return run_gsplit15(c, 0, a, b, ctw, ctw, false, c->d_relin, out, nl, count, 0u);
+  }
   if (c->logn > 14) return -1;
   if (c->sw.no_fused) return -1;
   if (!count) return 0;
@@ -1730,7 +1763,9 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     bool split = false;
     if constexpr (LB == 14) {
       split = all_fp(c) && !c->sw.no_split;
-      if (split && ckks)
+      if (split && ckks && use2 && !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= 192)
+        gsplit_front14(st, c, cc, nl, 1, tg, nullptr, target_stride, (double *)s.coef, (double *)s.dec, gelt);
+      else if (split && ckks)
         hipLaunchKernelGGL((gelt ? k_fused_operand_pass0_fp<LB, true, true> : k_fused_operand_pass0_fp<LB, true, false>),
                            dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, 0,
                            gelt, use2 ? 1 : 0);
@@ -1785,6 +1820,11 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
 // CKKS rotation with the Galois permutation folded into the key switch (N = 2^14, fp64 split path): in [count][2][nl][N]
 // NTT form; out = (g(c0) + ks0, ks1), ks = KeySwitch(g(c1)).  -1: not applicable, caller permutes first.
 int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *out, int nl, size_t count) {
+  if (c->logn == 15 && in != out && gsplit_applies(c, nl) && !c->sw.no_galois_fusion) {
+    if (!count) return 0;
+    const size_t pw15 = (size_t)nl * c->n;
+    return run_gsplit15(c, 1, in + pw15, in, 2 * pw15, 2 * pw15, false, key, out, nl, count, elt);
+  }
   if (c->logn != 14 || c->scheme != 2 || in == out) return -1;
   if (!all_fp(c) && !isplit_applies(c, nl)) return -1;
   if (c->sw.no_split || c->sw.no_fused || c->sw.no_galois_fusion) return -1;
@@ -1795,6 +1835,10 @@ int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *ou
 
 int keyswitch_fused(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count,
                     const u64 *addend, size_t addend_stride, bool add_c1) {
+  if (c->logn == 15 && gsplit_applies(c, nl)) {
+    if (!count) return 0;
+    return run_gsplit15(c, 1, target, addend, target_stride, addend_stride, add_c1, key, out, nl, count, 0u);
+  }
   if (c->logn > 14) return -1;
   if (c->sw.no_fused) return -1;
   if (!count) return 0;

@@ -1,0 +1,437 @@
+// abc_kernels_gsplit.hip -- the split key switch without any LDS-resident limb: N = 2^15 (a limb is 256 KiB, LDS is 160), and
+// the first step of the N = 2^14 sequence when too few ciphertexts are in flight to give every CU one of its 139 KiB workgroups.
+//
+// A 2^LOGN-point transform = NB = 2^(LOGN-10) blocks of 1024 points + a radix-NB "cross" pass over the NB values at one
+// position of every block.  Forward: cross pass (registers), then block tails; inverse: block tails, then cross pass.
+// So the whole CKKS key switch (and the multiply's front end) becomes
+//   G1a k_gsplit_inv_tails  (limb j, block; four ciphertexts per workgroup, one wavefront each): operand block (a1 b1 for a
+//                           multiply; the operand with the Galois gather folded in for a rotation) -> stages LOGN-1..LB of the
+//                           inverse transform in 8.5 KiB of LDS, inverse twiddles of the block in a shared LDS table -> hinv
+//   G1b k_gsplit_cross      (registers only): inverse cross pass, N^-1, canonical coefficient; per other key prime the forward
+//                           cross pass -> half-done decomposition limbs `part`
+//   G2a k_gsplit_special, G2b k_gsplit_pass, G2c k_gsplit_main: as k_split2_tailmac_fp (special prime) / k_split3_pass_fp /
+//                           k_split4_main_fp of abc_kernels_fused.hip with NB blocks and radix-NB cross passes
+// Same arithmetic as the N = 2^14 kernels (exact fp64 residues, primes < 2^50), bit-identical results
+// (tests/test_gpu_configs.py, tests/test_gpu_paths.py).  Replaces, for N = 2^15, the generic sequence (expand / strided
+// transform / inner product / tmod / finish kernels of abc_kernels_eval.hip: ~15 launches per rotation).
+//   SealCiphertext::multiply (src/runtime/SealCiphertext.cpp:102-107), rotateRows (:52-61), relinearize -> gsplit_chunk
+#include "abc_context.hpp"
+
+namespace abc {
+
+__device__ __forceinline__ double g_mulmod(double x, double y, double q, double qinv) {
+  const double h = x * y;
+  const double l = __builtin_fma(x, y, -h);
+  const double c = __builtin_rint(h * qinv);
+  return __builtin_fma(-c, q, h) + l;
+}
+
+// radix-2^R pass over the 2^R values one thread holds, one from each block (block index = array index): global stages 0..R-1
+template <int R>
+__device__ __forceinline__ void fwd_cross(double (&x)[1 << R], const FpTable &t, const FpK &kk) {
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      FpArith::fwd(x[k], x[k | half], tw_load(t.tw + (1 << u) + (k >> (R - u))), kk);
+    }
+  }
+}
+template <int R>
+__device__ __forceinline__ void inv_cross(double (&x)[1 << R], const FpTable &t, const FpK &kk) {
+#pragma unroll
+  for (int u = R - 1; u >= 0; u--) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      FpArith::inv(x[k], x[k | half], tw_load(t.itw + (1 << u) + (k >> (R - u))), kk);
+    }
+    if (R > 4 && u == R - 4) {  // X = a + b doubles per stage: four stages on centred values stay below 2^53, a fifth needs this
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) x[k] = fp_centre(x[k], kk.q, kk.qinv);
+    }
+  }
+}
+
+// ---- G1a ----
+// MODE 0: multiply (a, b: [ct][2][nl][N], operand = a1 b1).  MODE 1: operand in NTT form at a + ct * a_stride (Galois gather).
+template <int LOGN, int MODE, bool GAL>
+__global__ __launch_bounds__(256) void k_gsplit_inv_tails(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b,
+                                                          size_t a_stride, double *__restrict__ hinv, int nl, int cc, u32 gelt) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  extern __shared__ double dyn[];  // 4 transform buffers, then the block's inverse-twiddle table
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & (NB - 1);
+  const int j = (int)((blockIdx.x >> LOGNB) % (unsigned)nl);
+  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)nl) * 4 + (size_t)W;
+  const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps, pw = (size_t)nl * N;
+  const Mod m = mod_at(c, j);
+  const FpTable t = fp_table(c, j);
+  f64x2 *litw = reinterpret_cast<f64x2 *>(dyn + 4 * lds_words(10));
+  f64x2 twv[4];
+  block_twiddles_fetch<10, f64x2, 4>(t.itw, LOGNB, blk, (int)threadIdx.x, 256, twv);
+  const bool live = ct < (size_t)cc;  // wavefront-uniform
+  double x[16];
+  if (live) {  // PassIdx<10, 8, 2>: slot 4g + k = element 4 (lane + 64 g) + k
+    if (MODE == 0) {
+      const u64 *__restrict__ a1 = a + ct * 2 * pw + pw + (size_t)j * N + base, *__restrict__ b1 = b + ct * 2 * pw + pw + (size_t)j * N + base;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const u64 *pa = a1 + 4 * (lane + 64 * g), *pb = b1 + 4 * (lane + 64 * g);
+        const u64x2 a0v = reinterpret_cast<const u64x2 *>(pa)[0], a1v = reinterpret_cast<const u64x2 *>(pa)[1];
+        const u64x2 b0v = reinterpret_cast<const u64x2 *>(pb)[0], b1v = reinterpret_cast<const u64x2 *>(pb)[1];
+        x[4 * g + 0] = g_mulmod(fp_from_u64(a0v.x), fp_from_u64(b0v.x), m.qd, m.qinv);
+        x[4 * g + 1] = g_mulmod(fp_from_u64(a0v.y), fp_from_u64(b0v.y), m.qd, m.qinv);
+        x[4 * g + 2] = g_mulmod(fp_from_u64(a1v.x), fp_from_u64(b1v.x), m.qd, m.qinv);
+        x[4 * g + 3] = g_mulmod(fp_from_u64(a1v.y), fp_from_u64(b1v.y), m.qd, m.qinv);
+      }
+    } else {
+      const u64 *__restrict__ sp = a + ct * a_stride + (size_t)j * N;
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          x[4 * g + k] = fp_from_u64(sp[galois_ntt_src<GAL>((u32)(base + 4 * (lane + 64 * g) + k), gelt, LOGN)]);
+    }
+  }
+  block_twiddles_store<10, f64x2, 4>(litw, (int)threadIdx.x, 256, twv);
+  __syncthreads();
+  if (live) {
+    double *buf = dyn + W * lds_words(10);
+    double *__restrict__ dst = hinv + (ct * nl + j) * PS + base;
+    auto ld = [&](int r, int) { return x[r]; };
+    auto st = [&](int, int i, double v) { dst[i] = v; };
+    ntt_inv_block_a<10, FpArith, decltype(ld), decltype(st), true>(buf, ld, st, t, m, LOGNB, blk, lane, litw);
+  }
+}
+
+// ---- G1b ----
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__restrict__ hinv, double *__restrict__ part, int nl) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
+  const int j = (int)((blockIdx.x >> 2) % (unsigned)nl);
+  const size_t ct = (size_t)((blockIdx.x >> 2) / (unsigned)nl);
+  const size_t PS = (size_t)c.ps;
+  double x[NB];
+  {
+    const Mod m = mod_at(c, j);
+    const FpTable t = fp_table(c, j);
+    const FpK kk = FpArith::consts(m);
+    const double *__restrict__ src = hinv + (ct * nl + j) * PS;
+#pragma unroll
+    for (int k = 0; k < NB; k++) x[k] = fp_centre(src[(k << 10) + p], kk.q, kk.qinv);
+    inv_cross<LOGNB>(x, t, kk);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {  // canonical [0, q_j) as a double: the value SEAL's decomposition reduces modulo the other primes
+      const double w = fp_centre(fp_mul_lazy(x[k], m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
+      x[k] = w < 0.0 ? w + m.qd : w;
+    }
+  }
+  for (int I = 0; I <= nl; I++) {
+    if (I == j) continue;
+    const int ki = (I == nl) ? c.K - 1 : I;
+    const Mod m = mod_at(c, ki);
+    const FpTable t = fp_table(c, ki);
+    const FpK kk = FpArith::consts(m);
+    double y[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) y[k] = x[k];
+    fwd_cross<LOGNB>(y, t, kk);
+    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * PS;
+#pragma unroll
+    for (int k = 0; k < NB; k++) dst[(k << 10) + p] = y[k];
+  }
+}
+
+// ---- G2a: special prime (cf. k_split2_tailmac_fp, only_special) ----
+template <int LOGN, int NL>
+__global__ __launch_bounds__(NL * 64) void k_gsplit_special(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
+                                                            double *__restrict__ tsp_half) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, nl = NL;
+  extern __shared__ double dyn[];
+  const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & (NB - 1);
+  const size_t ct = (size_t)(blockIdx.x >> LOGNB);
+  const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps;
+  const int ki = c.K - 1;
+  const Mod m = mod_at(c, ki);
+  const FpTable t = fp_table(c, ki);
+  const double q = m.qd, qinv = m.qinv;
+  {
+    double *buf = dyn + J * lds_words(10);
+    const double *__restrict__ src = part + ((ct * (nl + 1) + nl) * nl + J) * PS + base;
+    ntt_fwd_block_a<10, FpArith>(
+        buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, LOGNB,
+        blk, lane);
+  }
+  __syncthreads();
+  for (int e = 2 * (int)threadIdx.x; e < 1024; e += 2 * (int)blockDim.x) {
+    double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
+#pragma unroll
+    for (int Jx = 0; Jx < NL; Jx++) {
+      const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
+      const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
+      const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
+      s0[0] += g_mulmod(v.x, fp_from_u64(k0.x), q, qinv);
+      s0[1] += g_mulmod(v.y, fp_from_u64(k0.y), q, qinv);
+      s1[0] += g_mulmod(v.x, fp_from_u64(k1.x), q, qinv);
+      s1[1] += g_mulmod(v.y, fp_from_u64(k1.y), q, qinv);
+    }
+    f64x2 r;
+    r.x = fp_centre(s0[0], q, qinv); r.y = fp_centre(s0[1], q, qinv);
+    *reinterpret_cast<f64x2 *>(dyn + lds_pad(e)) = r;
+    r.x = fp_centre(s1[0], q, qinv); r.y = fp_centre(s1[1], q, qinv);
+    *reinterpret_cast<f64x2 *>(dyn + lds_words(10) + lds_pad(e)) = r;
+  }
+  __syncthreads();
+  for (int comp = J; comp < 2; comp += nl) {
+    double *buf = dyn + comp * lds_words(10);
+    double *__restrict__ dst = tsp_half + (ct * 2 + comp) * PS + base;
+    ntt_inv_block_a<10, FpArith>(
+        buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, LOGNB, blk, lane);
+  }
+}
+
+// ---- G2b: special-prime limb back to coefficients (cross pass), + q_sp/2; forward cross pass of (t mod q_j + fix) per data prime ----
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_gsplit_pass(DevCtx c, const double *__restrict__ tsp_half, double *__restrict__ tpart, int nl) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  const size_t cc = blockIdx.x >> 2;
+  const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
+  const size_t PS = (size_t)c.ps;
+  double x[NB];
+  {
+    const Mod ms = mod_at(c, c.K - 1);
+    const FpTable ts = fp_table(c, c.K - 1);
+    const FpK ks = FpArith::consts(ms);
+    const double *__restrict__ src = tsp_half + cc * PS;
+#pragma unroll
+    for (int k = 0; k < NB; k++) x[k] = fp_centre(src[(k << 10) + p], ks.q, ks.qinv);
+    inv_cross<LOGNB>(x, ts, ks);
+    const double half = (double)(ms.q >> 1);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      const double w = fp_centre(fp_mul_lazy(x[k], ms.inv_n_c, ms.inv_n_cq, ms.qd) + half, ms.qd, ms.qinv);
+      x[k] = w < 0.0 ? w + ms.qd : w;
+    }
+  }
+  const u64 half = c.mods[c.K - 1].q >> 1;
+  for (int j = 0; j < nl; j++) {
+    const Mod m = mod_at(c, j);
+    const FpTable t = fp_table(c, j);
+    const FpK kk = FpArith::consts(m);
+    const u64 hm = reduce64(half, m);
+    const double fix = hm ? (double)(m.q - hm) : 0.0;
+    double y[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) y[k] = x[k] + fix;
+    fwd_cross<LOGNB>(y, t, kk);
+    double *__restrict__ dst = tpart + (cc * nl + j) * PS;
+#pragma unroll
+    for (int k = 0; k < NB; k++) dst[(k << 10) + p] = y[k];
+  }
+}
+
+// ---- G2c: main (cf. k_split4_main_fp) ----
+template <int MODE, int NL>
+struct GPairOps {
+  u64x2 k0[NL], k1[NL];
+  u64x2 a0, a1, b0, b1;
+  u64 xs[2], d0s[2], d1s[2];
+};
+
+template <int LOGN, int MODE, bool GAL, int NL>
+__global__ __launch_bounds__(512, 4) void k_gsplit_main(DevCtx c, const double *__restrict__ part, const double *__restrict__ tpart,
+                                                        const u64 *__restrict__ opa, const u64 *__restrict__ opb, size_t opa_stride,
+                                                        size_t opb_stride, int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out,
+                                                        u32 gelt) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, nl = NL, NT = 512, PER = 2;
+  extern __shared__ double dyn[];
+  static_assert(NL + 1 <= 8, "one wavefront per limb, eight wavefronts");
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & (NB - 1);
+  const int I = (int)((blockIdx.x >> LOGNB) % nl);
+  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / nl);
+  const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps;
+  const Mod m = mod_at(c, I);
+  const FpTable t = fp_table(c, I);
+  const double q = m.qd, qinv = m.qinv;
+  f64x2 *ltw = reinterpret_cast<f64x2 *>(dyn + (nl + 1) * lds_words(10));
+  const size_t pw = (size_t)nl * N;
+  const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
+  const double spc = cst->special_c[I], spq = cst->special_cq[I];
+  const double inv = cst->inv_special_c[I], inv_q = cst->inv_special_cq[I];
+
+  f64x2 twv[PER];
+  block_twiddles_fetch<10, f64x2, PER>(t.tw, LOGNB, blk, (int)threadIdx.x, NT, twv);
+  const bool has_limb = W <= nl;
+  const int Wc = has_limb ? W : 0;
+  const double *__restrict__ src = (Wc < nl - 1) ? part + ((ct * (nl + 1) + I) * nl + (Wc < I ? Wc : Wc + 1)) * PS + base
+                                                 : tpart + ((ct * 2 + (Wc - (nl - 1))) * nl + I) * PS + base;
+  double xin[16];
+  if (has_limb) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const f64x2 v = *reinterpret_cast<const f64x2 *>(src + (k << 7) + 2 * lane);
+      xin[k] = v.x;
+      xin[8 + k] = v.y;
+    }
+  }
+  const int e = 2 * (int)threadIdx.x;
+  GPairOps<MODE, NL> o;
+#pragma unroll
+  for (int Jx = 0; Jx < NL; Jx++) {
+    o.k0[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + I) * N + base + e);
+    o.k1[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + I) * N + base + e);
+  }
+  if (MODE == 0) {
+    const u64 *pa = opa + ct * 2 * pw + (size_t)I * N + base + e, *pb = opb + ct * 2 * pw + (size_t)I * N + base + e;
+    o.a0 = *reinterpret_cast<const u64x2 *>(pa); o.a1 = *reinterpret_cast<const u64x2 *>(pa + pw);
+    o.b0 = *reinterpret_cast<const u64x2 *>(pb); o.b1 = *reinterpret_cast<const u64x2 *>(pb + pw);
+  } else {
+    const u64 *xl = opa + ct * opa_stride + (size_t)I * N;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const u32 si = galois_ntt_src<GAL>((u32)(base + e + k), gelt, LOGN);
+      o.xs[k] = xl[si];
+      o.d0s[k] = o.d1s[k] = 0;
+      if (opb) {
+        const u64 *ad = opb + ct * opb_stride + (size_t)I * N;
+        o.d0s[k] = ad[si];
+        if (add_c1) o.d1s[k] = ad[pw + si];
+      }
+    }
+  }
+  block_twiddles_store<10, f64x2, PER>(ltw, (int)threadIdx.x, NT, twv);
+  __syncthreads();
+  if (has_limb) {
+    double *buf = dyn + W * lds_words(10);
+#pragma unroll
+    for (int r = 0; r < 16; r++) xin[r] = fp_centre(xin[r], q, qinv);
+    ntt_fwd_tail1024_pairs<FpArith>(buf, xin, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, LOGNB, blk, lane, ltw);
+  }
+  __syncthreads();
+  const double *tt0 = dyn + (nl - 1) * lds_words(10), *tt1 = dyn + nl * lds_words(10);
+  double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
+#pragma unroll
+  for (int Jx = 0; Jx < NL; Jx++) {
+    double x[2];
+    if (Jx == I) {
+      if (MODE == 0) {
+        const double x0[2] = {fp_from_u64(o.a0.x), fp_from_u64(o.a0.y)}, x1[2] = {fp_from_u64(o.a1.x), fp_from_u64(o.a1.y)};
+        const double y0[2] = {fp_from_u64(o.b0.x), fp_from_u64(o.b0.y)}, y1[2] = {fp_from_u64(o.b1.x), fp_from_u64(o.b1.y)};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          x[k] = g_mulmod(x1[k], y1[k], q, qinv);
+          d0[k] = g_mulmod(x0[k], y0[k], q, qinv);
+          d1[k] = g_mulmod(x0[k], y1[k], q, qinv) + g_mulmod(x1[k], y0[k], q, qinv);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          x[k] = fp_from_u64(o.xs[k]);
+          d0[k] = fp_from_u64(o.d0s[k]);
+          d1[k] = fp_from_u64(o.d1s[k]);
+        }
+      }
+    } else {
+      const int w = Jx < I ? Jx : Jx - 1;
+      const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + w * lds_words(10) + lds_pad(e));
+      x[0] = v.x;
+      x[1] = v.y;
+    }
+    s0[0] += g_mulmod(x[0], fp_from_u64(o.k0[Jx].x), q, qinv);
+    s0[1] += g_mulmod(x[1], fp_from_u64(o.k0[Jx].y), q, qinv);
+    s1[0] += g_mulmod(x[0], fp_from_u64(o.k1[Jx].x), q, qinv);
+    s1[1] += g_mulmod(x[1], fp_from_u64(o.k1[Jx].y), q, qinv);
+  }
+  const f64x2 u0 = *reinterpret_cast<const f64x2 *>(tt0 + lds_pad(e)), u1 = *reinterpret_cast<const f64x2 *>(tt1 + lds_pad(e));
+  u64x2 r;
+  r.x = fp_to_canon(fp_mul_lazy(s0[0] + fp_mul_lazy(d0[0], spc, spq, q) - u0.x, inv, inv_q, q), q, qinv);
+  r.y = fp_to_canon(fp_mul_lazy(s0[1] + fp_mul_lazy(d0[1], spc, spq, q) - u0.y, inv, inv_q, q), q, qinv);
+  *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 0) * nl + I) * N + base + e) = r;
+  r.x = fp_to_canon(fp_mul_lazy(s1[0] + fp_mul_lazy(d1[0], spc, spq, q) - u1.x, inv, inv_q, q), q, qinv);
+  r.y = fp_to_canon(fp_mul_lazy(s1[1] + fp_mul_lazy(d1[1], spc, spq, q) - u1.y, inv, inv_q, q), q, qinv);
+  *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
+}
+
+// ---- host side ----
+// first step only (the half-done decomposition limbs): used by the N = 2^14 sequence for small batches
+template <int LOGN>
+static void launch_gsplit_front(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb,
+                                size_t opa_stride, double *hinv, double *part, u32 gelt) {
+  constexpr int NB = 1 << (LOGN - 10);
+  const dim3 g1((unsigned)(((cc + 3) / 4) * nl * NB)), g2((unsigned)(cc * nl * 4));
+  const size_t lds = (size_t)(4 * lds_words(10)) * 8 + 1024 * 16;
+  if (mode == 0)
+    hipLaunchKernelGGL((k_gsplit_inv_tails<LOGN, 0, false>), g1, dim3(256), lds, st, c->dc, opa, opb, 0, hinv, nl, (int)cc, 0u);
+  else if (gelt)
+    hipLaunchKernelGGL((k_gsplit_inv_tails<LOGN, 1, true>), g1, dim3(256), lds, st, c->dc, opa, nullptr, opa_stride, hinv, nl, (int)cc, gelt);
+  else
+    hipLaunchKernelGGL((k_gsplit_inv_tails<LOGN, 1, false>), g1, dim3(256), lds, st, c->dc, opa, nullptr, opa_stride, hinv, nl, (int)cc, 0u);
+  hipLaunchKernelGGL((k_gsplit_cross<LOGN>), g2, dim3(256), 0, st, c->dc, hinv, part, nl);
+}
+void gsplit_front14(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb, size_t opa_stride,
+                    double *hinv, double *part, u32 gelt) {
+  launch_gsplit_front<14>(st, c, cc, nl, mode, opa, opb, opa_stride, hinv, part, gelt);
+}
+
+template <int LOGN>
+static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb,
+                               size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, double *part, double *tpart,
+                               double *tsp, u64 *out, u32 gelt) {
+  constexpr int NB = 1 << (LOGN - 10);
+  const size_t lds_sp = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
+  const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
+  const dim3 gsp((unsigned)(cc * NB)), gmain((unsigned)(cc * nl * NB));
+#define ABC_GSP(NLV)                                                                                                                    \
+  hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp);                            \
+  hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp, tpart, nl);                     \
+  if (mode == 0)                                                                                                                        \
+    hipLaunchKernelGGL((k_gsplit_main<LOGN, 0, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,  \
+                       opb_stride, add_c1, key, out, gelt);                                                                             \
+  else if (gelt)                                                                                                                        \
+    hipLaunchKernelGGL((k_gsplit_main<LOGN, 1, true, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,   \
+                       opb_stride, add_c1, key, out, gelt);                                                                             \
+  else                                                                                                                                  \
+    hipLaunchKernelGGL((k_gsplit_main<LOGN, 1, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,  \
+                       opb_stride, add_c1, key, out, gelt)
+  switch (nl) {
+    case 1: ABC_GSP(1); break;
+    case 2: ABC_GSP(2); break;
+    case 3: ABC_GSP(3); break;
+    default: ABC_GSP(4); break;
+  }
+#undef ABC_GSP
+}
+
+// scratch (words, limb stride c->dc.ps): hinv nl | part nl(nl+1) | tpart 2 nl | tsp_half 2
+size_t gsplit_scratch_words(const abc_hip_ctx *c, int nl) {
+  return ((size_t)nl + (size_t)nl * (nl + 1) + 2 * (size_t)nl + 2) * (size_t)c->dc.ps;
+}
+bool gsplit_applies(const abc_hip_ctx *c, int nl) {
+  if (c->logn != 15 || c->scheme != 2 || !c->use_fp || c->sw.no_gsplit || nl < 1 || nl > 4) return false;
+  for (int j = 0; j < c->K; j++)
+    if (!fp_ok(c->h_mods[j].bits)) return false;
+  return true;
+}
+// one chunk at N = 2^15: mode 0 multiply (opa = a, opb = b), mode 1 key switch (opa = operand in NTT form, opb = addend)
+int gsplit_chunk15(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb,
+                   size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt) {
+  const size_t PS = (size_t)c->dc.ps;
+  double *hinv = (double *)scratch, *part = hinv + cc * (size_t)nl * PS, *tpart = part + cc * (size_t)nl * (nl + 1) * PS,
+         *tsp = tpart + cc * 2 * (size_t)nl * PS;
+  launch_gsplit_front<15>(st, c, cc, nl, mode, opa, opb, opa_stride, hinv, part, gelt);
+  launch_gsplit_back<15>(st, c, cc, nl, mode, opa, opb, opa_stride, opb_stride, add_c1, key, part, tpart, tsp, out, gelt);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace abc

@@ -115,3 +115,38 @@ def test_bfv_default_8192_and_16384(oracle_mod, capi):
         _eq("BFVDefault(%d) mul_relin" % n, r, o.mul_relin(a, b))
         assert list(o.decode(o.decrypt(r))[:6]) == [0, 3, 2, 4, 50, 189]
         _eq("BFVDefault(%d) rotate" % n, g.rotate(a, 3), o.rotate(a, 3))
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_ckks15_every_level_split_and_generic(generic, oracle_mod, capi, monkeypatch):
+    """N = 2^15: the split key switch without LDS-resident limbs (abc_kernels_gsplit.hip) and the generic kernels it
+    replaces (ABC_HIP_NO_GSPLIT=1) against the oracle: multiply + relinearise, rotation (direct and NAF), relinearize and
+    key switch stand-alone, at every level, single and batched (ragged group of four in the block-tail kernel)."""
+    if generic:
+        monkeypatch.setenv("ABC_HIP_NO_GSPLIT", "1")
+    n = 32768
+    primes = oracle_mod.create_primes(n, [50, 40, 40, 40, 50])
+    o, g = _pair(oracle_mod, capi, oracle_mod.CKKS, n, primes, seed=0xABC00F15)
+    rng = np.random.default_rng(15)
+    L = 4
+    x = np.stack([rng.integers(0, q, size=(2, n), dtype=np.uint64) for q in primes[:L]], axis=1)
+    y = np.stack([rng.integers(0, q, size=(2, n), dtype=np.uint64) for q in primes[:L]], axis=1)
+    for j in range(L):  # adversarial residues: long runs at the ends of [0, q)
+        y[0, j, : n // 4] = primes[j] - 1
+        y[1, j, ::3] = 0
+    for level in range(L, 0, -1):
+        assert x.shape[1] == level
+        _eq("N=2^15 mul_relin level %d" % level, g.mul_relin(x, y), o.mul_relin(x, y))
+        _eq("N=2^15 rotate 1 level %d" % level, g.rotate(y, 1), o.rotate(y, 1))
+        _eq("N=2^15 rotate 5 (NAF) level %d" % level, g.rotate(x, 5), o.rotate(x, 5))
+        if level == L:
+            batch = np.stack([x, y, y, x, x])  # five pairs: one full group of four and a ragged one
+            got = g.mul_relin(batch, batch[::-1].copy())
+            _eq("N=2^15 batched mul_relin [1]", got[1], o.mul_relin(y, x))
+            _eq("N=2^15 batched mul_relin [4]", got[4], o.mul_relin(x, x))
+            _eq("N=2^15 batched rotate [2]", g.rotate(batch, -64)[2], o.rotate(y, -64))
+            t3 = o.multiply(x, y)
+            _eq("N=2^15 relinearize", g.relinearize(t3), o.relinearize(t3))
+        if level > 1:
+            x, y = o.mod_switch(x), o.mod_switch(y)
+    g.close()

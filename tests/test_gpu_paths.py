@@ -17,6 +17,7 @@ VARIANTS = {
     "integer_v1": {"ABC_HIP_NO_FP64": "1", "ABC_HIP_NO_ISPLIT": "1"},  # round-1 integer sequence (LDS-resident transforms)
     "fp64_unsplit": {"ABC_HIP_NO_SPLIT": "1"},
     "fp64_separate_kernels": {"ABC_HIP_NO_SPLIT": "1", "ABC_HIP_NO_TENSOR_DECOMP": "1"},
+    "fp64_fat_front": {"ABC_HIP_NO_LEAN_FRONT": "1"},  # the 139 KiB tensor / operand kernel even for small batches
     "fp64_split_v1": {"ABC_HIP_NO_SPLIT2": "1"},  # round-1 kernels: four launches, LDS-atomic accumulators
     "fp64_split_v2": {"ABC_HIP_NO_SPLIT3": "1"},  # three launches, LDS-resident mod-down
     "fp64_split_serial_tail": {"ABC_HIP_TAILMAC_SERIAL": "1", "ABC_HIP_NO_SPLIT2": "1"},
@@ -92,7 +93,7 @@ def test_ckks14_paths_bit_exact(variant, oracle14, capi, monkeypatch):
     g.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
+@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
 def test_ckks14_every_level_bit_exact(variant, oracle14, capi, monkeypatch):
     """multiply + relinearise and rotate at data levels 4, 3, 2 and 1 (the cooperative tail kernel runs nl wavefronts)"""
     o, primes, ins, want = oracle14
@@ -219,7 +220,7 @@ def test_ckks14_wide_prime_chains_every_level(chain, isplit, oracle_mod, capi, m
 # several chunks per lane: the hot call splits a batch into chunks that alternate over internal streams and reuse
 # per-lane scratch; every pair of a batch that spans chunk boundaries is checked, also with `out` aliasing `a`
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["default", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
+@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
 def test_multi_chunk_batches_every_pair(variant, oracle14, capi, monkeypatch):
     import ctypes as C
     o, primes, ins, want = oracle14
