@@ -179,13 +179,33 @@ static int build_context(abc_hip_ctx *c) {
   std::vector<uint64_t> Bp;
   uint64_t m_sk = 0, gamma = 0;
   if (bfv) {
-    // BEHZ auxiliary base sizes as in SEAL's RNSTool
+    // BEHZ auxiliary base, sized by SEAL's RNSTool rule.  SEAL draws m_sk, gamma and B from the 61-bit NTT primes.  The
+    // q-residues a BFV multiply returns do not depend on which auxiliary primes carry the intermediate values (every
+    // step computes residues of one fixed integer -- DESIGN.md section 4c; shown on the oracle by
+    // tests/test_oracle_internal.py and on the device by every BFV parity test, whose oracle keeps SEAL's base), so where
+    // every ciphertext prime is below 2^50 the base is drawn from the 50-bit primes instead: all BEHZ transforms then
+    // take the exact-fp64 butterflies (8 instead of 16 instructions).  gamma (decryption only) stays SEAL's.
+    bool fp_aux = !env_on("ABC_HIP_NO_FP64") && !env_on("ABC_HIP_BEHZ_SEAL_BASE");
+    for (uint64_t q : c->primes) fp_aux = fp_aux && fp_ok((u32)bitlen(q));
+    const int aux_bits = fp_aux ? 50 : 61;
     int nB = L;
-    if (32 + bitlen(c->t) + prod_bitlen(qs) >= 61 * L + 61) nB++;
-    auto aux = ntt_primes(N, 61, (size_t)nB + 2);
-    m_sk = aux[0];
-    gamma = aux[1];
-    Bp.assign(aux.begin() + 2, aux.end());
+    if (32 + bitlen(c->t) + prod_bitlen(qs) >= aux_bits * L + aux_bits) nB++;
+    gamma = ntt_primes(N, 61, 2)[1];
+    if (!fp_aux) {
+      auto aux = ntt_primes(N, 61, (size_t)nB + 2);
+      m_sk = aux[0];
+      Bp.assign(aux.begin() + 2, aux.end());
+    } else {
+      std::vector<uint64_t> alt;
+      for (uint64_t p : ntt_primes(N, 50, (size_t)nB + 1 + (size_t)K)) {
+        bool clash = false;
+        for (uint64_t q : c->primes) clash = clash || (p == q);
+        if (!clash && alt.size() < (size_t)nB + 1) alt.push_back(p);
+      }
+      if (alt.size() < (size_t)nB + 1) throw std::runtime_error("not enough 50-bit NTT primes for the BEHZ auxiliary base");
+      m_sk = alt[0];
+      Bp.assign(alt.begin() + 1, alt.end());
+    }
     c->nB = nB;
     c->nBsk = nB + 1;
     for (uint64_t b : Bp) c->mod_values.push_back(b);

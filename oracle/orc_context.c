@@ -104,11 +104,34 @@ static orc_behz *behz_create(int logn, const orc_mod *q, int nq, uint64_t t) {
   orc_mod_init(&b->t, t);
   int t_bits = 0; { uint64_t v = t; while (v) { t_bits++; v >>= 1; } }
   int total_bits = product_bit_count(q, nq);
+  /* SEAL takes m_sk, gamma and B from the 61-bit NTT primes.  ORC_BEHZ_AUX_BITS=<bits> (tests only) builds m_sk and B
+   * from primes of another size instead -- same sizing rule, primes of the ciphertext modulus skipped, gamma unchanged
+   * (it only serves decryption) -- to demonstrate that the q-residues a BFV multiply returns do not depend on which
+   * auxiliary primes carry the intermediate values (tests/test_oracle_internal.py). */
+  int aux_bits = 61;
+  { const char *e = getenv("ORC_BEHZ_AUX_BITS"); if (e && atoi(e) >= 30 && atoi(e) <= 61) aux_bits = atoi(e); }
   int nB = nq;
-  if (32 + t_bits + total_bits >= 61 * nq + 61) nB++;
+  if (32 + t_bits + total_bits >= aux_bits * nq + aux_bits) nB++;
   b->nB = nB; b->nBsk = nB + 1;
   uint64_t aux[ORC_MAX_LIMBS + 2];
-  if (orc_get_primes(n, 61, nB + 2, aux)) { free(b); return NULL; }
+  uint64_t seal_aux[2];
+  if (orc_get_primes(n, 61, 2, seal_aux)) { free(b); return NULL; }
+  if (aux_bits == 61) {
+    if (orc_get_primes(n, 61, nB + 2, aux)) { free(b); return NULL; }
+  } else {
+    uint64_t cand[2 * ORC_MAX_LIMBS + 4];
+    if (orc_get_primes(n, aux_bits, nB + 1 + nq + 1, cand)) { free(b); return NULL; }
+    int got = 0;
+    aux[1] = seal_aux[1];
+    for (int i = 0; i < nB + 1 + nq + 1 && got < nB + 1; i++) {
+      int clash = 0;
+      for (int k = 0; k < nq; k++) clash |= (cand[i] == q[k].q);
+      if (clash) continue;
+      aux[got == 0 ? 0 : got + 1] = cand[i];
+      got++;
+    }
+    if (got < nB + 1) { free(b); return NULL; }
+  }
   orc_mod_init(&b->m_sk, aux[0]);
   orc_mod_init(&b->gamma, aux[1]);
   for (int i = 0; i < nB; i++) { orc_mod_init(&b->B[i], aux[2 + i]); b->Bsk[i] = b->B[i]; }

@@ -90,3 +90,34 @@ def test_sampler_spec_is_deterministic(oracle_mod):
     assert np.array_equal(a.relin_key(), b.relin_key())
     b.keygen(12)
     assert not np.array_equal(a.relin_key(), b.relin_key())
+
+
+def test_bfv_multiply_does_not_depend_on_the_auxiliary_base(oracle_mod):
+    """BEHZ: every step of the multiply computes residues of one fixed integer, so the q-residues of the result must be the
+    same whichever auxiliary primes carry the intermediate values.  SEAL draws m_sk and B from the 61-bit primes; the HIP
+    backend draws them from the 50-bit ones where that puts every BEHZ transform on its exact-fp64 path.  Here: the oracle
+    with ORC_BEHZ_AUX_BITS = 50 / 45 against the oracle with SEAL's base, on ordinary and on adversarial ciphertexts."""
+    import os
+    rng = np.random.default_rng(61)
+    for n in (4096, 8192):
+        primes, t = oracle_mod.default_bfv_primes(n), oracle_mod.plain_modulus_batching(n, 20)
+        os.environ.pop("ORC_BEHZ_AUX_BITS", None)
+        ref = oracle_mod.Oracle(oracle_mod.BFV, n, primes, t)
+        ref.keygen(3)
+        L = len(primes) - 1
+        a = ref.encrypt(ref.encode(oracle_mod.expand_vector([3, 3, 1, 4, 5, 9], n)), 1)
+        b = ref.encrypt(ref.encode(oracle_mod.expand_vector([0, 1, 2, 1, 10, 21], n)), 2)
+        ex = np.stack([rng.integers(0, q, size=(2, n), dtype=np.uint64) for q in primes[:L]], axis=1)
+        for j in range(L):
+            ex[0, j, : n // 2] = primes[j] - 1
+            ex[1, j, ::2] = 0
+        want = [ref.multiply(a, b), ref.multiply(ex, ex), ref.multiply(a, ex)]
+        for bits in (50, 45):
+            os.environ["ORC_BEHZ_AUX_BITS"] = str(bits)
+            try:
+                alt = oracle_mod.Oracle(oracle_mod.BFV, n, primes, t)
+            finally:
+                os.environ.pop("ORC_BEHZ_AUX_BITS", None)
+            got = [alt.multiply(a, b), alt.multiply(ex, ex), alt.multiply(a, ex)]
+            for w, g_ in zip(want, got):
+                assert np.array_equal(w, g_), (n, bits)
