@@ -32,6 +32,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_split4 = env_on("ABC_HIP_NO_SPLIT4");
   s.no_isplit = env_on("ABC_HIP_NO_ISPLIT");
   s.no_gsplit = env_on("ABC_HIP_NO_GSPLIT");
+  s.no_bsplit = env_on("ABC_HIP_NO_BSPLIT");
   s.no_lean_front = env_on("ABC_HIP_NO_LEAN_FRONT");
   s.split4_special = env_on("ABC_HIP_SPLIT4_SPECIAL");
   s.no_tensor_decomp = env_on("ABC_HIP_NO_TENSOR_DECOMP");

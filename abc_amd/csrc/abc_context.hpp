@@ -140,7 +140,7 @@ struct abc_hip_ctx {
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
   struct Switches {
-    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
+    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, no_bsplit = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
     bool tailmac_serial = false, no_galois_fusion = false;
     size_t chunk = 0, few_limbs = 48;
     int lanes = 2;
@@ -226,6 +226,9 @@ int gsplit_chunk15(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int 
                    size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt);
 void gsplit_front14(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb, size_t opa_stride,
                     double *hinv, double *part, u32 gelt);
+bool bsplit_applies(const abc_hip_ctx *c, int nl);
+int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
+                  size_t addend_stride, int add_c1, u64 *out);
 // integer twins of the split kernels (abc_kernels_isplit.hip)
 bool isplit_applies(const abc_hip_ctx *c, int nl);
 size_t isplit_scratch_words(const abc_hip_ctx *c, int nl);

@@ -1746,7 +1746,8 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     return run_isplit(c, 1, target, addend, target_stride, addend_stride, add_c1, key, out, nl, count, gelt);
   const ChunkPlan p = plan_chunks(c, nl, count);
   const bool use2 = LB == 14 && ckks && all_fp(c) && !c->sw.no_split && !c->sw.no_split2 && nl <= 12;
-  const size_t SN = use2 ? (size_t)c->dc.ps : N;
+  const bool useb = LB == 14 && !ckks && !c->sw.no_split && bsplit_applies(c, nl);  // BFV: abc_kernels_gsplit.hip, k_bsplit_finish
+  const size_t SN = (use2 || useb) ? (size_t)c->dc.ps : N;
   const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
   LaneScope scope(c, p.lanes);
@@ -1771,10 +1772,16 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
                            gelt, use2 ? 1 : 0);
       else if (split && cc * nl < 128)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl * (nl + 1))), dim3((1 << LB) / 16), 0, st,
-                           c->dc, tg, target_stride, (double *)s.dec, nl, 1, 0u, 0);
+                           c->dc, tg, target_stride, (double *)s.dec, nl, 1, 0u, useb ? 1 : 0);
       else if (split)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
-                           target_stride, (double *)s.dec, nl, 0, 0u, 0);
+                           target_stride, (double *)s.dec, nl, 0, 0u, useb ? 1 : 0);
+      if (split && useb) {  // inner product + inverse tails for every key prime, then the register-only finish
+        if (bsplit_back14(c, st, cc, nl, (const double *)s.dec, (double *)s.ksacc, key, addend ? addend + off * addend_stride : nullptr,
+                          addend_stride, add_c1 ? 1 : 0, out + off * 2 * nl * N))
+          return 1;
+        continue;
+      }
     }
     if constexpr (LB == 14) {
       if (split && ckks && !c->sw.no_split2 && nl <= 12) {

@@ -149,7 +149,11 @@ __global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__
 }
 
 // ---- G2a: special prime (cf. k_split2_tailmac_fp, only_special) ----
-template <int LOGN, int NL>
+// ALL = false: the special prime only (CKKS: the data primes go through k_gsplit_main); output [ct][comp] limbs.
+// ALL = true (BFV, operand in coefficient form: no diagonal term, no NTT-form output): every key prime I = 0..nl, grid
+//   (ct, I, block); the inverse-transform tails of BOTH the special limb and the accumulated data limbs; output
+//   [ct][I][comp] limbs -- k_bsplit_finish does the rest.
+template <int LOGN, int NL, bool ALL>
 __global__ __launch_bounds__(NL * 64) void k_gsplit_special(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
                                                             double *__restrict__ tsp_half) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, nl = NL;
@@ -157,15 +161,16 @@ __global__ __launch_bounds__(NL * 64) void k_gsplit_special(DevCtx c, const doub
   const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int blk = blockIdx.x & (NB - 1);
-  const size_t ct = (size_t)(blockIdx.x >> LOGNB);
+  const int I = ALL ? (int)((blockIdx.x >> LOGNB) % (unsigned)(nl + 1)) : nl;
+  const size_t ct = ALL ? (size_t)((blockIdx.x >> LOGNB) / (unsigned)(nl + 1)) : (size_t)(blockIdx.x >> LOGNB);
   const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps;
-  const int ki = c.K - 1;
+  const int ki = (I == nl) ? c.K - 1 : I;
   const Mod m = mod_at(c, ki);
   const FpTable t = fp_table(c, ki);
   const double q = m.qd, qinv = m.qinv;
   {
     double *buf = dyn + J * lds_words(10);
-    const double *__restrict__ src = part + ((ct * (nl + 1) + nl) * nl + J) * PS + base;
+    const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * PS + base;
     ntt_fwd_block_a<10, FpArith>(
         buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, LOGNB,
         blk, lane);
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(NL * 64) void k_gsplit_special(DevCtx c, const doub
   __syncthreads();
   for (int comp = J; comp < 2; comp += nl) {
     double *buf = dyn + comp * lds_words(10);
-    double *__restrict__ dst = tsp_half + (ct * 2 + comp) * PS + base;
+    double *__restrict__ dst = tsp_half + (ALL ? (ct * (nl + 1) + I) * 2 + comp : ct * 2 + comp) * PS + base;
     ntt_inv_block_a<10, FpArith>(
         buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, LOGNB, blk, lane);
   }
@@ -392,7 +397,7 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
   const dim3 gsp((unsigned)(cc * NB)), gmain((unsigned)(cc * nl * NB));
 #define ABC_GSP(NLV)                                                                                                                    \
-  hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp);                            \
+  hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp);                            \
   hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp, tpart, nl);                     \
   if (mode == 0)                                                                                                                        \
     hipLaunchKernelGGL((k_gsplit_main<LOGN, 0, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,  \
@@ -430,6 +435,90 @@ int gsplit_chunk15(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int 
          *tsp = tpart + cc * 2 * (size_t)nl * PS;
   launch_gsplit_front<15>(st, c, cc, nl, mode, opa, opb, opa_stride, hinv, part, gelt);
   launch_gsplit_back<15>(st, c, cc, nl, mode, opa, opb, opa_stride, opb_stride, add_c1, key, part, tpart, tsp, out, gelt);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// ---- BFV (coefficient-form ciphertexts), N = 2^14: the key switch behind k_fused_operand_pass0_fp<14, false, false> ----
+// k_gsplit_special<14, NL, true> leaves, per (ct, key prime, component), the accumulated limb after stages 13..4 of its inverse
+// transform.  This kernel (registers only) finishes both the data limb I and the special limb (cross pass, N^-1; the special
+// one + q_sp/2, canonical) and forms  out = (INTT_I(acc) - (t mod q_I + fix)) q_sp^-1 (+ addend)  in coefficient form --
+// k_fused_ks_moddown_bfv_fp without its 139 KiB workgroup.
+__global__ __launch_bounds__(256) void k_bsplit_finish(DevCtx c, const double *__restrict__ half, const u64 *__restrict__ addend,
+                                                       size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl) {
+  constexpr int LOGN = 14, NB = 16;
+  const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
+  const int I = (int)((blockIdx.x >> 2) % (unsigned)nl);
+  const size_t cc = (size_t)((blockIdx.x >> 2) / (unsigned)nl);  // ct*2 + comp
+  const size_t ct = cc >> 1;
+  const int comp = (int)(cc & 1);
+  const size_t N = (size_t)1 << LOGN, PS = (size_t)c.ps;
+  double t[NB], x[NB];
+  {
+    const Mod ms = mod_at(c, c.K - 1);
+    const FpTable ts = fp_table(c, c.K - 1);
+    const FpK ks = FpArith::consts(ms);
+    const double *__restrict__ src = half + ((ct * (nl + 1) + nl) * 2 + comp) * PS;
+#pragma unroll
+    for (int k = 0; k < NB; k++) t[k] = fp_centre(src[(k << 10) + p], ks.q, ks.qinv);
+    inv_cross<4>(t, ts, ks);
+    const double hq = (double)(ms.q >> 1);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      const double w = fp_centre(fp_mul_lazy(t[k], ms.inv_n_c, ms.inv_n_cq, ms.qd) + hq, ms.qd, ms.qinv);
+      t[k] = w < 0.0 ? w + ms.qd : w;  // canonical [0, q_sp)
+    }
+  }
+  const Mod m = mod_at(c, I);
+  const FpTable tb = fp_table(c, I);
+  const FpK kk = FpArith::consts(m);
+  {
+    const double *__restrict__ src = half + ((ct * (nl + 1) + I) * 2 + comp) * PS;
+#pragma unroll
+    for (int k = 0; k < NB; k++) x[k] = fp_centre(src[(k << 10) + p], kk.q, kk.qinv);
+    inv_cross<4>(x, tb, kk);
+  }
+  const u64 hm = reduce64(c.mods[c.K - 1].q >> 1, m);
+  const double fix = hm ? (double)(m.q - hm) : 0.0;
+  const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
+  const double inv = cst->inv_special_c[I], inv_q = cst->inv_special_cq[I];
+  u64 *__restrict__ o = out + (cc * nl + I) * N;
+  const bool add = addend && (comp == 0 || add_c1);
+  const u64 *__restrict__ cin = add ? addend + ct * addend_stride + ((size_t)comp * nl + I) * N : nullptr;
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const double d = fp_mul_lazy(x[k], m.inv_n_c, m.inv_n_cq, m.qd) - (t[k] + fix);
+    double r = fp_mul_lazy(d, inv, inv_q, m.qd);
+    if (add) r += fp_from_u64(cin[(k << 10) + p]);
+    o[(k << 10) + p] = fp_to_canon(r, m.qd, m.qinv);
+  }
+}
+
+// half: [cc][nl+1][2] limbs at stride c->dc.ps; part as written by k_fused_operand_pass0_fp<14, false, false> (padded layout)
+bool bsplit_applies(const abc_hip_ctx *c, int nl) {
+  if (c->logn != 14 || c->scheme != 1 || !c->use_fp || c->sw.no_bsplit || nl < 1 || nl > 8) return false;
+  for (int j = 0; j < c->K; j++)
+    if (!fp_ok(c->h_mods[j].bits)) return false;
+  return true;
+}
+int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
+                  size_t addend_stride, int add_c1, u64 *out) {
+  const dim3 g((unsigned)(cc * (nl + 1) * 16));
+  const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
+#define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<14, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half)
+  switch (nl) {
+    case 1: ABC_BSP(1); break;
+    case 2: ABC_BSP(2); break;
+    case 3: ABC_BSP(3); break;
+    case 4: ABC_BSP(4); break;
+    case 5: ABC_BSP(5); break;
+    case 6: ABC_BSP(6); break;
+    case 7: ABC_BSP(7); break;
+    default: ABC_BSP(8); break;
+  }
+#undef ABC_BSP
+  hipLaunchKernelGGL(k_bsplit_finish, dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, addend, addend_stride, add_c1, out,
+                     nl);
   ABC_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -116,7 +116,11 @@ def test_ckks14_every_level_bit_exact(variant, oracle14, capi, monkeypatch):
     g.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "integer_transforms", "fp64_unsplit"])
+VARIANTS["bfv_v1_keyswitch"] = {"ABC_HIP_NO_BSPLIT": "1"}  # LDS-atomic tail kernel + LDS-resident mod-down (round 1)
+VARIANTS["bfv_seal_aux_base"] = {"ABC_HIP_BEHZ_SEAL_BASE": "1"}  # 61-bit BEHZ auxiliary primes, as SEAL draws them
+
+
+@pytest.mark.parametrize("variant", ["default", "bfv_v1_keyswitch", "bfv_seal_aux_base", "integer_transforms", "fp64_unsplit"])
 def test_bfv14_keyswitch_paths_bit_exact(variant, oracle_mod, capi, monkeypatch):
     """BFVDefault(16384): 48/49-bit primes, i.e. the re-centring ('red') fp64 butterflies, coefficient-form operand"""
     for k, v in VARIANTS[variant].items():
@@ -139,6 +143,16 @@ def test_bfv14_keyswitch_paths_bit_exact(variant, oracle_mod, capi, monkeypatch)
     got = g.multiply_plain(batch, pl)
     _same(variant + " bfv multiply_plain batch[1]", got[1], o.multiply_plain(ex, pl))
     _same(variant + " bfv multiply_plain batch[2]", got[2], o.multiply_plain(ct, pl))
+    # batched key switches: 40 ciphertexts (more than 128 (ciphertext, limb) pairs: the one-workgroup-per-limb register pass),
+    # mixed ordinary / adversarial, rotation by a step that needs the NAF decomposition
+    big = np.stack([ct if i % 3 else ex for i in range(40)])
+    rot = g.rotate(big, -5)
+    _same(variant + " bfv batched rotate [0]", rot[0], o.rotate(ex, -5))
+    _same(variant + " bfv batched rotate [39]", rot[39], o.rotate(ex, -5))
+    _same(variant + " bfv batched rotate [1]", rot[1], o.rotate(ct, -5))
+    mr = g.mul_relin(big, big[::-1].copy())
+    _same(variant + " bfv batched mul_relin [1]", mr[1], o.mul_relin(ct, ct))
+    _same(variant + " bfv batched mul_relin [0]", mr[0], o.mul_relin(ex, ex))
     g.close()
 
 
