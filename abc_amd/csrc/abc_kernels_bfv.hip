@@ -288,14 +288,16 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
   const int L = c->L, nBsk = c->nBsk, nlm = L + nBsk;
   // per ciphertext pair (words): aq,bq 2*2L ; aB,bB 2*2nBsk ; dq 3L ; dB 3nBsk
   const size_t per_ct = (size_t)(4 * L + 4 * nBsk + 3 * L + 3 * nBsk) * N;
-  size_t chunk = (((size_t)4 << 30) / 8) / per_ct;  // scratch capped at 4 GiB
+  size_t budget = (size_t)4 << 30;  // scratch capped at 4 GiB (ABC_HIP_BFV_SCRATCH_MB: test knob, forces several chunks)
+  if (c->sw.bfv_scratch_mb) budget = c->sw.bfv_scratch_mb << 20;
+  size_t chunk = (budget / 8) / per_ct;
   if (chunk < 1) chunk = 1;
   if (chunk > count) chunk = count;
   else if (count % chunk && count / chunk < 8) chunk = (count + count / chunk) / (count / chunk + 1);  // even chunks, no runt
   if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
-  u64 *aq = (u64 *)c->ws, *bq = aq + chunk * 2 * L * N;
-  u64 *aB = bq + chunk * 2 * L * N, *bB = aB + chunk * 2 * nBsk * N;
-  u64 *dq = bB + chunk * 2 * nBsk * N, *dB = dq + chunk * 3 * L * N;
+  u64 *aq = (u64 *)c->ws;
+  u64 *aB = aq + chunk * 4 * L * N;
+  u64 *dq = aB + chunk * 4 * nBsk * N, *dB = dq + chunk * 3 * L * N;
   const LimbMap qmap = key_limb_map(c, L);
   LimbMap bmap{};
   for (int j = 0; j < nBsk; j++) bmap.id[j] = c->dc.id_bsk + j;
@@ -303,7 +305,12 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
   for (size_t off = 0; off < count; off += chunk) {
     const size_t cc = (count - off < chunk) ? count - off : chunk;
     const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
-    launch_behz_extend(c, pa, pb, aB, cc * 4);  // aB and bB are adjacent: one launch for both operands
+    // both operands go through one launch each of the extension and of the transforms, which write [a polys | b polys]
+    // back to back: the b halves therefore start cc (not chunk) ciphertexts behind the a halves.  (Round 1 used the fixed
+    // chunk offset here, which is only the same thing when the last chunk is full: a ragged last chunk -- 125 pairs at
+    // N = 2^16 split 63 + 62 -- read stale b operands.  Found by running config 5 at its stated per-GPU batch.)
+    u64 *bq = aq + cc * 2 * L * N, *bB = aB + cc * 2 * nBsk * N;
+    launch_behz_extend(c, pa, pb, aB, cc * 4);
     ABC_HIP_CHECK(hipGetLastError());
     // operands stay intact: transform out of place, both operands in one launch (aq and bq are adjacent)
     if (launch_ntt_fwd_from2(c, pa, pb, aq, qmap, L, cc * 4 * L)) return 1;

@@ -160,3 +160,23 @@ def test_bfv_naf_rotations_compose(capi, n):
     for steps in (3, -3, 7, 11, -13, 100, row - 1, -(row - 1), 1365, -2047):
         got = _dec(g, g.rotate(ca, steps)).reshape(2, row)
         assert np.array_equal(got, np.roll(rows, -steps, axis=1)), steps
+
+
+def test_bfv_multiply_ragged_last_chunk(capi, monkeypatch):
+    """bfv_multiply processes a batch in chunks bounded by its scratch budget and runs both operands through one launch per
+    step; with a ragged last chunk the second operand's staging area starts earlier than with a full one.  (Round 1 got that
+    wrong; it only shows when the batch does not divide evenly -- N = 2^16 with 125 pairs -- so it is forced here on a small
+    ring through the scratch budget knob.)  Every row of the batched product must equal the single-pair product."""
+    monkeypatch.setenv("ABC_HIP_BFV_SCRATCH_MB", "64")
+    n = 8192
+    g = _bfv(capi, n)
+    t = g.t
+    rng = np.random.default_rng(125)
+    B = 23
+    a = rng.integers(-(t // 2), t // 2, size=(B, n))
+    b = rng.integers(-(t // 2), t // 2, size=(B, n))
+    ca, cb = _enc(g, a, 1), _enc(g, b, 500)
+    prod = g.mul_relin(ca, cb)
+    assert np.array_equal(_dec(g, prod), _centre(a.astype(object) * b, t).astype(np.int64))
+    for i in (0, B // 2, B - 1):
+        assert np.array_equal(g.mul_relin(ca[i], cb[i]), prod[i])
