@@ -180,3 +180,23 @@ def test_bfv_multiply_ragged_last_chunk(capi, monkeypatch):
     assert np.array_equal(_dec(g, prod), _centre(a.astype(object) * b, t).astype(np.int64))
     for i in (0, B // 2, B - 1):
         assert np.array_equal(g.mul_relin(ca[i], cb[i]), prod[i])
+
+
+@pytest.mark.parametrize("n,B", [(32768, 20), (65536, 40)])
+def test_big_ring_batches_equal_single_calls(capi, n, B):
+    """N > 2^14 (generic kernels, their scratch budget forces several chunks with a ragged tail at these batch sizes): every
+    sampled row of a batched mul_relin / rotate must equal the same operation on that row alone, and decrypt correctly."""
+    g = _bfv(capi, n)
+    t = g.t
+    rng = np.random.default_rng(n + B)
+    a = rng.integers(-(t // 2), t // 2, size=(B, n))
+    b = rng.integers(-(t // 2), t // 2, size=(B, n))
+    ca, cb = _enc(g, a, 7), _enc(g, b, 900)
+    prod = g.mul_relin(ca, cb)
+    assert np.array_equal(_dec(g, prod), _centre(a.astype(object) * b, t).astype(np.int64))
+    rot = g.rotate(ca, 3)
+    row = n // 2
+    assert np.array_equal(_dec(g, rot).reshape(B, 2, row), np.roll(a.reshape(B, 2, row), -3, axis=2))
+    for i in (0, B // 2 + 1, B - 1):
+        assert np.array_equal(g.mul_relin(ca[i], cb[i]), prod[i])
+        assert np.array_equal(g.rotate(ca[i], 3), rot[i])
