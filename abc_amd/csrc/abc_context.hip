@@ -208,6 +208,8 @@ static int build_context(abc_hip_ctx *c) {
       m_sk = alt[0];
       Bp.assign(alt.begin() + 1, alt.end());
     }
+    // sums of up to L + 1 (resp. nB + 1) lazily reduced terms must stay below 2^53: 12 x 0.625 x 2^50
+    c->behz_fp = fp_aux && L <= 10 && !env_on("ABC_HIP_BEHZ_INT_KERNELS");
     c->nB = nB;
     c->nBsk = nB + 1;
     for (uint64_t b : Bp) c->mod_values.push_back(b);
@@ -351,12 +353,46 @@ static int build_context(abc_hip_ctx *c) {
   read_switches(c);
   ABC_HIP_CHECK(hipMalloc(&c->d_cst, sizeof(DevConst)));
   ABC_HIP_CHECK(hipMemcpy(c->d_cst, &k, sizeof(DevConst), hipMemcpyHostToDevice));
+  if (bfv && c->behz_fp) {
+    // {centred value, value / p} pairs of every BEHZ constant
+    auto pair = [](double (&dst)[2], uint64_t v, uint64_t p) {
+      const double vc = v > p / 2 ? -(double)(p - v) : (double)v;
+      dst[0] = vc;
+      dst[1] = vc / (double)p;
+    };
+    std::vector<DevConstFp> hf(1);
+    DevConstFp &f = hf[0];
+    std::memset(&f, 0, sizeof(f));
+    const int nB = c->nB, nBsk = c->nBsk;
+    std::vector<uint64_t> bskv(Bp);
+    bskv.push_back(m_sk);
+    for (int i = 0; i < L; i++) {
+      pair(f.ext_q[i], k.ext_q[i], qs[i]);
+      pair(f.flr_q[i], k.flr_q[i], qs[i]);
+      pair(f.B_mod_q[i], k.B_mod_q[i], qs[i]);
+      for (int b = 0; b < nB; b++) pair(f.B_to_q[i][b], k.B_to_q[i][b], qs[i]);
+    }
+    for (int j = 0; j < nBsk; j++) {
+      for (int i = 0; i < L; i++) pair(f.q_to_bsk[j][i], k.q_to_bsk[j][i], bskv[j]);
+      pair(f.q_mod_bsk[j], k.q_mod_bsk[j], bskv[j]);
+      pair(f.inv_mtilde_mod_bsk[j], k.inv_mtilde_mod_bsk[j], bskv[j]);
+      pair(f.tinvq_bsk[j], k.tinvq_bsk[j], bskv[j]);
+      pair(f.inv_q_mod_bsk[j], k.inv_q_mod_bsk[j], bskv[j]);
+    }
+    for (int b = 0; b < nB; b++) {
+      pair(f.inv_punct_B[b], k.inv_punct_B[b], Bp[b]);
+      pair(f.B_to_msk[b], k.B_to_msk[b], m_sk);
+    }
+    pair(f.inv_B_mod_msk, k.inv_B_mod_msk, m_sk);
+    ABC_HIP_CHECK(hipMalloc(&c->d_cstf, sizeof(DevConstFp)));
+    ABC_HIP_CHECK(hipMemcpy(c->d_cstf, &f, sizeof(DevConstFp), hipMemcpyHostToDevice));
+  }
   if (bfv) {
     ABC_HIP_CHECK(hipMalloc(&c->d_slot_map, N * 4));
     ABC_HIP_CHECK(hipMemcpy(c->d_slot_map, slot_map.data(), N * 4, hipMemcpyHostToDevice));
   }
   DevCtx &dc = c->dc;
-  dc.mods = c->d_mods; dc.tw = c->d_tw; dc.ftw = c->d_ftw; dc.cst = c->d_cst; dc.slot_map = c->d_slot_map;
+  dc.mods = c->d_mods; dc.tw = c->d_tw; dc.ftw = c->d_ftw; dc.cst = c->d_cst; dc.cstf = c->d_cstf; dc.slot_map = c->d_slot_map;
   dc.logn = logn; dc.n = (int)N; dc.K = K; dc.L = L;
   dc.ps = (int)N;
   if (const char *e = std::getenv("ABC_HIP_SCRATCH_PAD")) dc.ps = (int)N + (std::atoi(e) / 2) * 2;  // words, kept even (16-byte rows)
@@ -625,7 +661,8 @@ void abc_hip_ctx_destroy(abc_hip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  (void)hipFree(c->d_mods); (void)hipFree(c->d_tw); (void)hipFree(c->d_ftw); (void)hipFree(c->d_cst); (void)hipFree(c->d_slot_map);
+  (void)hipFree(c->d_mods); (void)hipFree(c->d_tw); (void)hipFree(c->d_ftw); (void)hipFree(c->d_cst); (void)hipFree(c->d_cstf);
+  (void)hipFree(c->d_slot_map);
   (void)hipFree(c->d_sk); (void)hipFree(c->d_pk); (void)hipFree(c->d_relin);
   for (auto &kv : c->d_galois) (void)hipFree(kv.second);
   (void)hipFree(c->ws);

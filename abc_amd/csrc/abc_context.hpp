@@ -60,12 +60,23 @@ struct DevConst {
   u64 neg_inv_q_mod_t, neg_inv_q_mod_gamma, inv_gamma_mod_t, gamma;
 };
 
+// fp64 twins of the BEHZ constants ({value centred into (-p/2, p/2], value / p}: the operand pair of fp_mul_lazy), filled
+// when every ciphertext prime and every auxiliary prime is below 2^50 (abc_kernels_bfv.hip, k_behz_extend_fp / k_behz_floor_fp)
+struct DevConstFp {
+  double ext_q[kMaxLimbs][2], flr_q[kMaxLimbs][2], B_mod_q[kMaxLimbs][2];
+  double q_to_bsk[kMaxLimbs][kMaxLimbs][2];  // [j][i]
+  double B_to_q[kMaxLimbs][kMaxLimbs][2];    // [i][b]
+  double q_mod_bsk[kMaxLimbs][2], inv_mtilde_mod_bsk[kMaxLimbs][2], tinvq_bsk[kMaxLimbs][2], inv_q_mod_bsk[kMaxLimbs][2];
+  double inv_punct_B[kMaxLimbs][2], B_to_msk[kMaxLimbs][2], inv_B_mod_msk[2];
+};
+
 // passed BY VALUE to every kernel
 struct DevCtx {
   const Mod *mods;      // [nmods]
   const u64 *tw;        // [nmods][2][N][2]: forward {w, Shoup} pairs, then inverse pairs
   const double *ftw;    // same shape, fp64 twin {w centred, w / q}; filled for primes < 2^50 only
   const DevConst *cst;  //
+  const DevConstFp *cstf;  // null unless the BEHZ base is fp64-capable
   const u32 *slot_map;  // [N] BatchEncoder index map (BFV)
   int logn, n;
   int ps;               // scratch limb stride of the split kernels in words: n + pad (HBM channel spread)
@@ -136,6 +147,7 @@ struct abc_hip_ctx {
   std::unordered_map<void *, bool> parked;
   std::unordered_map<size_t, std::vector<void *>> cap_free;
   std::unordered_map<void *, bool> cap_born;  // allocated during the running capture
+  bool behz_fp = false;  // BFV: 50-bit BEHZ auxiliary base and fp64 base-conversion kernels
   bool use_fp = true;  // fp64 transforms for primes < 2^50 (ABC_HIP_NO_FP64=1 forces the integer path)
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
@@ -147,6 +159,7 @@ struct abc_hip_ctx {
     unsigned lane_offset_us = 0;
   } sw;
   abc::DevConst *d_cst = nullptr;
+  abc::DevConstFp *d_cstf = nullptr;
   uint32_t *d_slot_map = nullptr;
   // keys (device)
   uint64_t *d_sk = nullptr, *d_pk = nullptr, *d_relin = nullptr;

@@ -183,6 +183,107 @@ __global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, con
   }
 }
 
+
+// ---- fp64 twins of the two BEHZ kernels (every ciphertext prime and every auxiliary prime below 2^50) ----
+// Same steps, same integers: each modular product is fp_mul_lazy on an integer-valued double (exact while magnitudes stay
+// below 2^53), sums of up to 16 lazily reduced terms are exact, and every value the algorithm uses AS AN INTEGER (the
+// residues summed by the fast base conversions, r mod m~, alpha) is brought to its canonical representative first --
+// 6 DP instructions per term of a conversion instead of 10 integer ones.
+__device__ __forceinline__ double fp_canon_d(double x, double q, double qinv) {  // any lazy value -> canonical [0, q) as a double
+  const double r = fp_centre(x, q, qinv);
+  return r < 0.0 ? r + q : r;
+}
+template <int LT, int NBT>
+__global__ __launch_bounds__(256) void k_behz_extend_fp(DevCtx c, const u64 *in, const u64 *in2, u64 *out, size_t polys) {
+  const ABC_CONST_AS DevConst &k = *(const ABC_CONST_AS DevConst *)c.cst;
+  const ABC_CONST_AS DevConstFp &f = *(const ABC_CONST_AS DevConstFp *)c.cstf;
+  const int L = LT ? LT : k.nq, nBsk = LT ? NBT + 1 : k.nBsk;
+  const size_t items = polys * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, x = it & (c.n - 1);
+    const bool second = in2 && p >= polys / 2;
+    const u64 *src = second ? in2 : in;
+    const size_t pp = second ? p - polys / 2 : p;
+    double tmp[LT ? LT : kMaxLimbs];
+    u32 mt = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const Mod m = mod_at(c, i);
+      const double v = fp_canon_d(fp_mul_lazy(fp_from_u64(src[(pp * L + i) * c.n + x]), f.ext_q[i][0], f.ext_q[i][1], m.qd), m.qd, m.qinv);
+      tmp[i] = v;
+      mt += (u32)(u64)v * (u32)k.q_to_mtilde[i];  // arithmetic mod 2^32 on the canonical residue
+    }
+    const u32 r32 = mt * (u32)k.neg_inv_q_mod_mtilde;
+    const double r = (double)(int)r32;  // centred representative of r mod m~ (r32 >= 2^31 -> r32 - 2^32)
+    u64 dep = (u64)r32;  // keeps every iteration's constant loads inside the iteration (row_after)
+#pragma unroll
+    for (int j = 0; j < nBsk; j++) {
+      const Mod m = mod_at(c, c.id_bsk + j);
+      const ABC_CONST_AS double *row = row_after(&f.q_to_bsk[j][0][0], dep);
+      double conv = fp_mul_lazy(r, f.q_mod_bsk[j][0], f.q_mod_bsk[j][1], m.qd);
+#pragma unroll
+      for (int i = 0; i < L; i++) conv += fp_mul_lazy(tmp[i], row[2 * i], row[2 * i + 1], m.qd);
+      dep = fp_to_canon(fp_mul_lazy(conv, f.inv_mtilde_mod_bsk[j][0], f.inv_mtilde_mod_bsk[j][1], m.qd), m.qd, m.qinv);
+      out[(p * nBsk + j) * c.n + x] = dep;
+    }
+  }
+}
+template <int LT, int NBT>
+__global__ __launch_bounds__(256) void k_behz_floor_fp(DevCtx c, const u64 *dq, const u64 *dB, u64 *out, size_t polys) {
+  const ABC_CONST_AS DevConst &k = *(const ABC_CONST_AS DevConst *)c.cst;
+  const ABC_CONST_AS DevConstFp &f = *(const ABC_CONST_AS DevConstFp *)c.cstf;
+  const int L = LT ? LT : k.nq, nB = LT ? NBT : k.nB, nBsk = nB + 1;
+  const size_t items = polys * c.n;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const Mod msk = mod_at(c, c.id_bsk + nB);
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += stride) {
+    const size_t p = it >> c.logn, x = it & (c.n - 1);
+    double tq[LT ? LT : kMaxLimbs], fl[LT ? NBT + 1 : kMaxLimbs + 1];
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const Mod m = mod_at(c, i);
+      tq[i] = fp_canon_d(fp_mul_lazy(fp_from_u64(dq[(p * L + i) * c.n + x]), f.flr_q[i][0], f.flr_q[i][1], m.qd), m.qd, m.qinv);
+    }
+    u64 dep = (u64)__double_as_longlong(tq[L - 1]);
+#pragma unroll
+    for (int j = 0; j < nBsk; j++) {
+      const Mod m = mod_at(c, c.id_bsk + j);
+      const ABC_CONST_AS double *row = row_after(&f.q_to_bsk[j][0][0], dep);
+      double conv = 0.0;
+#pragma unroll
+      for (int i = 0; i < L; i++) conv += fp_mul_lazy(tq[i], row[2 * i], row[2 * i + 1], m.qd);
+      // (dB*t - conv) * q^-1 = dB*(t q^-1) - conv*q^-1
+      const double xb = fp_mul_lazy(fp_from_u64(dB[(p * nBsk + j) * c.n + x]), f.tinvq_bsk[j][0], f.tinvq_bsk[j][1], m.qd);
+      fl[j] = xb - fp_mul_lazy(conv, f.inv_q_mod_bsk[j][0], f.inv_q_mod_bsk[j][1], m.qd);
+      dep = (u64)__double_as_longlong(fl[j]);
+    }
+    double tb[LT ? NBT : kMaxLimbs];
+#pragma unroll
+    for (int b2 = 0; b2 < nB; b2++) {
+      const Mod m = mod_at(c, c.id_bsk + b2);
+      tb[b2] = fp_canon_d(fp_mul_lazy(fl[b2], f.inv_punct_B[b2][0], f.inv_punct_B[b2][1], m.qd), m.qd, m.qinv);
+    }
+    double mconv = -fl[nB];
+#pragma unroll
+    for (int b2 = 0; b2 < nB; b2++) mconv += fp_mul_lazy(tb[b2], f.B_to_msk[b2][0], f.B_to_msk[b2][1], msk.qd);
+    // alpha = (conv - x_msk) B^-1 mod m_sk, as the signed integer in [-(m_sk-1)/2, (m_sk-1)/2] Shenoy-Kumaresan subtracts
+    double alpha = fp_canon_d(fp_mul_lazy(mconv, f.inv_B_mod_msk[0], f.inv_B_mod_msk[1], msk.qd), msk.qd, msk.qinv);
+    if (alpha > (double)(msk.q >> 1)) alpha -= msk.qd;
+    dep = (u64)__double_as_longlong(alpha);
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const Mod m = mod_at(c, i);
+      const ABC_CONST_AS double *row = row_after(&f.B_to_q[i][0][0], dep);
+      double v = -fp_mul_lazy(alpha, f.B_mod_q[i][0], f.B_mod_q[i][1], m.qd);
+#pragma unroll
+      for (int b2 = 0; b2 < nB; b2++) v += fp_mul_lazy(tb[b2], row[2 * b2], row[2 * b2 + 1], m.qd);
+      dep = fp_to_canon(v, m.qd, m.qinv);
+      out[(p * L + i) * c.n + x] = dep;
+    }
+  }
+}
+
 // ---- BEHZ steps (4)-(5) for rings that fit LDS: dyadic tensor product fused into the load of the inverse transform ----
 // workgroup (ct, comp, limb): d_comp = a0 b0 | a0 b1 + a1 b0 | a1 b1 of limb `limb`, inverse transform in LDS, coefficient
 // form to d [count][3][nlm][N].  Saves the tensor kernels' round trip (7 limb transfers per limb and ciphertext).
@@ -275,9 +376,17 @@ static int tensor_intt(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d, const
     else hipLaunchKernelGGL((KERNEL<0, 0>), GRID, dim3(256), 0, c->stream, __VA_ARGS__);                                \
   } while (0)
 static void launch_behz_extend(abc_hip_ctx *c, const u64 *in, const u64 *in2, u64 *out, size_t polys) {
+  if (c->behz_fp) {
+    ABC_BEHZ_DISPATCH(k_behz_extend_fp, dim3(grid_for(polys * c->n, 256)), c->dc, in, in2, out, polys);
+    return;
+  }
   ABC_BEHZ_DISPATCH(k_behz_extend, dim3(grid_for(polys * c->n, 256)), c->dc, in, in2, out, polys);
 }
 static void launch_behz_floor(abc_hip_ctx *c, const u64 *dq, const u64 *dB, u64 *out, size_t polys) {
+  if (c->behz_fp) {
+    ABC_BEHZ_DISPATCH(k_behz_floor_fp, dim3(grid_for(polys * c->n, 256)), c->dc, dq, dB, out, polys);
+    return;
+  }
   ABC_BEHZ_DISPATCH(k_behz_floor, dim3(grid_for(polys * c->n, 256)), c->dc, dq, dB, out, polys);
 }
 
