@@ -46,6 +46,12 @@ HipCiphertext::HipCiphertext(const std::reference_wrapper<const HipCiphertextFac
       buf(allocate(hipFactory.get(), hipFactory.get().dataLimbs())), nl(hipFactory.get().dataLimbs()),
       sc(hipFactory.get().isCkks() ? hipFactory.get().defaultScale() : 1.0) {}
 
+HipCiphertext::HipCiphertext(const std::reference_wrapper<const HipCiphertextFactory> hipFactory, int level, double scale)
+    : AbstractCiphertext((const std::reference_wrapper<const AbstractCiphertextFactory>)hipFactory),
+      buf(allocate(hipFactory.get(), level)), nl(level), sc(scale) {
+  if (level < 1 || level > hipFactory.get().dataLimbs()) throw std::runtime_error("HipCiphertext: level out of range");
+}
+
 HipCiphertext::~HipCiphertext() = default;
 
 // "deep copy" by value semantics: shares the buffer until one side writes

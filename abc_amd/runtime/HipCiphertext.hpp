@@ -51,6 +51,8 @@ class HipCiphertext : public AbstractCiphertext {
  public:
   ~HipCiphertext() override;
   explicit HipCiphertext(const std::reference_wrapper<const HipCiphertextFactory> hipFactory);
+  // uninitialised value at a given level and scale (the factory fills it: loadCiphertext)
+  HipCiphertext(const std::reference_wrapper<const HipCiphertextFactory> hipFactory, int level, double scale);
   HipCiphertext(const HipCiphertext &other);
   HipCiphertext(HipCiphertext &&other) noexcept;
   HipCiphertext &operator=(const HipCiphertext &other);

@@ -5,6 +5,7 @@
 
 #include "../../include/abc_hip.h"
 #include "HipCiphertext.hpp"
+#include "SealWire.hpp"
 
 HipCiphertextFactory::HipCiphertextFactory() { setupContext(0); }
 
@@ -75,6 +76,7 @@ void HipCiphertextFactory::setupContext(int device) {
   abcHipCheck(abc_hip_ctx_create(ckksMode ? ABC_HIP_SCHEME_CKKS : ABC_HIP_SCHEME_BFV, logn, primes, count, t, device, &ctx), "context");
   limbs = count - 1;
   chain.assign(primes, primes + count);
+  plainModulus = t;
   if (ckksMode) ckksEncoder = CkksEncoder(ciphertextSlotSize, std::vector<uint64_t>(primes, primes + limbs));
   // fresh keys per factory, like seal::KeyGenerator: OS-keyed ChaCha20 unless a TEST seed asks for the reproducible spec
   if (keySeed) abcHipCheck(abc_hip_keygen(ctx, keySeed), "key generation");
@@ -330,4 +332,194 @@ void HipCiphertextFactory::rewriteCiphertext(AbstractCiphertext &target, const s
   abcHipCheck(abc_hip_memcpy_d2d(ctx, const_cast<uint64_t *>(static_cast<const HipCiphertext &>(dst).devicePtr()),
                                  dynamic_cast<const HipCiphertext &>(*fresh).devicePtr(), ciphertextWords() * 8),
               "rewrite ciphertext");
+}
+
+// ---- SEAL 3.6 wire format ----
+namespace {
+sealwire::Parms wireParms(bool ckks, unsigned int n, const std::vector<uint64_t> &chain, uint64_t t) {
+  sealwire::Parms p;
+  p.scheme = ckks ? 2 : 1;
+  p.ringDegree = n;
+  p.primes = chain;
+  p.plainModulus = ckks ? 0 : t;
+  return p;
+}
+sealwire::Compression wireMode(int compression) {
+  if (compression < 0 || compression > 2) throw std::runtime_error("SEAL wire format: compression must be 0 (none), 1 (zlib) or 2 (zstd)");
+  return (sealwire::Compression)compression;
+}
+}  // namespace
+
+void HipCiphertextFactory::saveCiphertext(const AbstractCiphertext &ciphertext, std::ostream &out, int compression) const {
+  const auto &c = dynamic_cast<const HipCiphertext &>(ciphertext);
+  if (&c.getFactory() != this) throw std::runtime_error("saveCiphertext: ciphertext belongs to another factory");
+  const size_t N = ciphertextSlotSize, per = (size_t)2 * c.level() * N;
+  std::vector<uint64_t> host(batch * per);
+  abcHipCheck(abc_hip_memcpy_d2h(ctx, host.data(), c.devicePtr(), host.size() * 8), "ciphertext download");
+  sealwire::CiphertextImage img;
+  // a ciphertext names the parameter set of ITS level: the first `level` data primes
+  img.id = sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), (size_t)c.level());
+  img.nttForm = ckksMode;  // SEAL keeps BFV ciphertexts in coefficient form and CKKS ones in NTT form; so does this backend
+  img.size = 2;
+  img.ringDegree = N;
+  img.limbs = (uint64_t)c.level();
+  img.scale = ckksMode ? c.scale() : 1.0;
+  for (size_t b = 0; b < batch; ++b) {
+    img.data.assign(host.begin() + b * per, host.begin() + (b + 1) * per);
+    sealwire::save(out, img, wireMode(compression));
+  }
+}
+
+std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::loadCiphertext(std::istream &in) const {
+  const size_t N = ciphertextSlotSize;
+  const sealwire::Parms parms = wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus);
+  std::vector<uint64_t> host;
+  int level = 0;
+  double scale = 1.0;
+  for (size_t b = 0; b < batch; ++b) {
+    sealwire::CiphertextImage img;
+    sealwire::load(in, img, (uint64_t)3 * chain.size() * N);
+    int found = 0;
+    for (int l = limbs; l >= 1 && !found; --l)
+      if (img.id == sealwire::parmsId(parms, (size_t)l)) found = l;
+    if (!found) throw std::runtime_error("loadCiphertext: parms_id matches no level of this factory's parameters (scheme, N, primes, t)");
+    if (img.size != 2) throw std::runtime_error("loadCiphertext: only relinearised (size 2) ciphertexts travel through the plugin surface");
+    if (img.ringDegree != N || img.limbs != (uint64_t)found) throw std::runtime_error("loadCiphertext: dimensions contradict parms_id");
+    if (img.nttForm != ckksMode) throw std::runtime_error("loadCiphertext: unexpected representation (BFV: coefficient form, CKKS: NTT form)");
+    if (b == 0) {
+      level = found;
+      scale = ckksMode ? img.scale : 1.0;
+      host.reserve(batch * img.data.size());
+    } else if (found != level || (ckksMode && img.scale != scale)) {
+      throw std::runtime_error("loadCiphertext: the instances of one batched value must share level and scale");
+    }
+    for (size_t j = 0; j < (size_t)found; ++j)
+      for (int comp = 0; comp < 2; ++comp)
+        for (size_t i = 0; i < N; ++i)
+          if (img.data[((size_t)comp * found + j) * N + i] >= chain[j]) throw std::runtime_error("loadCiphertext: residue not reduced modulo its prime");
+    host.insert(host.end(), img.data.begin(), img.data.end());
+  }
+  auto c = std::make_unique<HipCiphertext>(std::cref(*this), level, scale);
+  abcHipCheck(abc_hip_memcpy_h2d(ctx, c->devicePtr(), host.data(), host.size() * 8), "ciphertext upload");
+  return c;
+}
+
+void HipCiphertextFactory::saveSecretKey(std::ostream &out, int compression) const {
+  const size_t N = ciphertextSlotSize, K = chain.size();
+  sealwire::PlaintextImage img;
+  img.id = sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K);
+  img.coeffCount = K * N;
+  img.scale = 1.0;
+  img.data.resize(K * N);
+  abcHipCheck(abc_hip_get_secret_key(ctx, img.data.data()), "secret key download");
+  sealwire::save(out, img, wireMode(compression));
+  std::fill(img.data.begin(), img.data.end(), 0);
+}
+void HipCiphertextFactory::loadSecretKey(std::istream &in) {
+  const size_t N = ciphertextSlotSize, K = chain.size();
+  sealwire::PlaintextImage img;
+  sealwire::load(in, img, (uint64_t)K * N);
+  if (img.id != sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K))
+    throw std::runtime_error("loadSecretKey: parms_id is not this factory's key-level parameter set");
+  if (img.coeffCount != K * N) throw std::runtime_error("loadSecretKey: expected N coefficients per key prime (NTT form)");
+  const int rc = abc_hip_load_secret_key(ctx, img.data.data());
+  std::fill(img.data.begin(), img.data.end(), 0);
+  abcHipCheck(rc, "secret key upload");
+}
+
+namespace {
+sealwire::CiphertextImage keyImage(const sealwire::ParmsId &id, size_t N, size_t K, const uint64_t *words) {
+  sealwire::CiphertextImage img;
+  img.id = id;
+  img.nttForm = true;
+  img.size = 2;
+  img.ringDegree = N;
+  img.limbs = K;
+  img.scale = 1.0;
+  img.data.assign(words, words + 2 * K * N);
+  return img;
+}
+void checkKeyImage(const sealwire::CiphertextImage &img, const sealwire::ParmsId &id, size_t N, size_t K, const char *what) {
+  if (img.id != id) throw std::runtime_error(std::string(what) + ": parms_id is not this factory's key-level parameter set");
+  if (!img.nttForm || img.size != 2 || img.ringDegree != N || img.limbs != K)
+    throw std::runtime_error(std::string(what) + ": expected a size-2 NTT-form key over all key primes");
+}
+}  // namespace
+
+void HipCiphertextFactory::savePublicKey(std::ostream &out, int compression) const {
+  const size_t N = ciphertextSlotSize, K = chain.size();
+  std::vector<uint64_t> words(2 * K * N);
+  abcHipCheck(abc_hip_get_public_key(ctx, words.data()), "public key download");
+  const auto id = sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K);
+  sealwire::save(out, keyImage(id, N, K, words.data()), wireMode(compression));
+}
+void HipCiphertextFactory::loadPublicKey(std::istream &in) {
+  const size_t N = ciphertextSlotSize, K = chain.size();
+  sealwire::CiphertextImage img;
+  sealwire::load(in, img, (uint64_t)2 * K * N);
+  checkKeyImage(img, sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K), N, K, "loadPublicKey");
+  abcHipCheck(abc_hip_load_public_key(ctx, img.data.data()), "public key upload");
+}
+
+void HipCiphertextFactory::saveRelinKeys(std::ostream &out, int compression) const {
+  const size_t N = ciphertextSlotSize, K = chain.size(), per = 2 * K * N;
+  std::vector<uint64_t> words((size_t)limbs * per);
+  abcHipCheck(abc_hip_get_relin_key(ctx, words.data()), "relinearisation key download");
+  sealwire::KSwitchImage img;
+  img.id = sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K);
+  img.keys.resize(1);  // seal::RelinKeys: entry 0 <-> the key for s^2
+  for (int j = 0; j < limbs; ++j) img.keys[0].push_back(keyImage(img.id, N, K, words.data() + (size_t)j * per));
+  sealwire::save(out, img, wireMode(compression));
+}
+void HipCiphertextFactory::loadRelinKeys(std::istream &in) {
+  const size_t N = ciphertextSlotSize, K = chain.size(), per = 2 * K * N;
+  sealwire::KSwitchImage img;
+  sealwire::load(in, img, (uint64_t)(limbs + 1) * per);
+  const auto id = sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K);
+  if (img.id != id) throw std::runtime_error("loadRelinKeys: parms_id is not this factory's key-level parameter set");
+  if (img.keys.empty() || img.keys[0].size() != (size_t)limbs)
+    throw std::runtime_error("loadRelinKeys: expected one entry (s^2) with one key per data prime");
+  std::vector<uint64_t> words;
+  words.reserve((size_t)limbs * per);
+  for (const auto &pk : img.keys[0]) {
+    checkKeyImage(pk, id, N, K, "loadRelinKeys");
+    words.insert(words.end(), pk.data.begin(), pk.data.end());
+  }
+  abcHipCheck(abc_hip_load_relin_key(ctx, words.data()), "relinearisation key upload");
+}
+
+void HipCiphertextFactory::saveGaloisKeys(std::ostream &out, int compression) const {
+  const size_t N = ciphertextSlotSize, K = chain.size(), per = 2 * K * N;
+  sealwire::KSwitchImage img;
+  img.id = sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K);
+  img.keys.resize(N);  // seal::GaloisKeys: entry (galois_elt - 1) / 2, empty where no key was generated
+  std::vector<uint64_t> words((size_t)limbs * per);
+  const int count = abc_hip_num_galois_keys(ctx);
+  for (int k = 0; k < count; ++k) {
+    const uint32_t elt = abc_hip_galois_elt_at(ctx, k);
+    abcHipCheck(abc_hip_get_galois_key(ctx, elt, words.data()), "Galois key download");
+    auto &entry = img.keys[(elt - 1) >> 1];
+    for (int j = 0; j < limbs; ++j) entry.push_back(keyImage(img.id, N, K, words.data() + (size_t)j * per));
+  }
+  sealwire::save(out, img, wireMode(compression));
+}
+void HipCiphertextFactory::loadGaloisKeys(std::istream &in) {
+  const size_t N = ciphertextSlotSize, K = chain.size(), per = 2 * K * N;
+  sealwire::KSwitchImage img;
+  sealwire::load(in, img, (uint64_t)64 * (limbs + 1) * per);
+  const auto id = sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K);
+  if (img.id != id) throw std::runtime_error("loadGaloisKeys: parms_id is not this factory's key-level parameter set");
+  if (img.keys.size() != N) throw std::runtime_error("loadGaloisKeys: expected N entries (one per odd Galois element below 2N)");
+  std::vector<uint64_t> words;
+  for (size_t idx = 0; idx < N; ++idx) {
+    const auto &entry = img.keys[idx];
+    if (entry.empty()) continue;
+    if (entry.size() != (size_t)limbs) throw std::runtime_error("loadGaloisKeys: expected one key per data prime");
+    words.clear();
+    for (const auto &pk : entry) {
+      checkKeyImage(pk, id, N, K, "loadGaloisKeys");
+      words.insert(words.end(), pk.data.begin(), pk.data.end());
+    }
+    abcHipCheck(abc_hip_load_galois_key(ctx, (uint32_t)(2 * idx + 1), words.data()), "Galois key upload");
+  }
 }

@@ -6,6 +6,7 @@
 #pragma once
 
 #include <deque>
+#include <iosfwd>
 #include <string>
 #include <vector>
 
@@ -55,6 +56,7 @@ class HipCiphertextFactory : public AbstractCiphertextFactory, public GraphCapab
   double ckksScale = 0;
   std::vector<int> ckksBits;
   std::vector<uint64_t> chain;  // the context's primes: data limbs, then the special prime
+  uint64_t plainModulus = 0;    // BFV t (0 for CKKS)
   CkksEncoder ckksEncoder;
   struct CachedCkksPlain {
     std::vector<double> values;
@@ -119,6 +121,23 @@ class HipCiphertextFactory : public AbstractCiphertextFactory, public GraphCapab
   std::unique_ptr<AbstractCiphertext> createCiphertext(std::unique_ptr<AbstractValue> &&abstractValue) const override;
   void decryptCiphertext(AbstractCiphertext &abstractCiphertext, std::vector<int64_t> &ciphertextData) const override;
   std::string getString(AbstractCiphertext &abstractCiphertext) const override;
+
+  // ---- SEAL 3.6 wire format (SealWire.hpp: layout, provenance; PARITY UNPINNED -- no SEAL in this image) ----
+  // The reference serialises nothing; this is the additive row f3 of SURVEY.md section 8: a client may keep seal::KeyGenerator /
+  // Encryptor / Decryptor and hand evaluation to this backend.  compression: 0 none, 1 zlib, 2 zstd (seal::compr_mode_type).
+  // A batched value is written / read as its B instances, one SEAL object after the other.
+  void saveCiphertext(const AbstractCiphertext &ciphertext, std::ostream &out, int compression = 0) const;
+  std::unique_ptr<AbstractCiphertext> loadCiphertext(std::istream &in) const;
+  void saveSecretKey(std::ostream &out, int compression = 0) const;
+  void savePublicKey(std::ostream &out, int compression = 0) const;
+  void saveRelinKeys(std::ostream &out, int compression = 0) const;
+  void saveGaloisKeys(std::ostream &out, int compression = 0) const;
+  // replace this factory's keys by SEAL-generated ones (same parameters, checked through parms_id); seed-compressed objects
+  // (Serializable<...>) are refused
+  void loadSecretKey(std::istream &in);
+  void loadPublicKey(std::istream &in);
+  void loadRelinKeys(std::istream &in);
+  void loadGaloisKeys(std::istream &in);
 
   // GraphCapable: recorded circuits (abc_hip_graph_*)
   void graphBegin() const override;

@@ -25,7 +25,7 @@ echo "built $OUT/ref_dummy_driver"
 RT="$HERE/../abc_amd/runtime"
 if [ -f "$HERE/../abc_amd/libabc_hip.so" ]; then
   g++ $CXXFLAGS -DABC_HIP_USE_REFERENCE_HEADERS -I"$RT" "$HERE/ref_hip_dropin.cpp" "$RT/HipCiphertext.cpp" \
-      "$RT/HipCiphertextFactory.cpp" "$OUT/libabc_ref.a" -L"$HERE/../abc_amd" -labc_hip \
+      "$RT/HipCiphertextFactory.cpp" "$RT/SealWire.cpp" "$OUT/libabc_ref.a" -L"$HERE/../abc_amd" -labc_hip -lz -ldl \
       -Wl,-rpath,'$ORIGIN/../../abc_amd' -o "$OUT/ref_hip_dropin"
   echo "built $OUT/ref_hip_dropin"
 fi
