@@ -366,7 +366,8 @@ static int tensor_intt(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d, const
   }
 }
 
-// shapes of BFVDefault(4096 / 8192 / 16384) and of config 5 get fully unrolled kernels
+// shapes of BFVDefault(4096 / 8192 / 16384) and of config 5 get fully unrolled kernels (the L = 8, nB = 9 shape was tried:
+// slower than the generic loop form, 658 against 740 circuits/s on config 5 with a 50-bit chain)
 #define ABC_BEHZ_DISPATCH(KERNEL, GRID, ...)                                                                          \
   do {                                                                                                                  \
     const int L_ = c->L, nB_ = c->nB;                                                                                   \

@@ -83,8 +83,10 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_ntt_inv_fp(DevCtx c, u64 *da
 }
 
 // first R stages of a 2^logn-point forward transform, straight through HBM (coalesced: lane = p)
+// (src, src2, split as in the block kernels: limbs [0, split) are read from src, the rest from src2; in place: src == data)
 template <int R>
-__global__ __launch_bounds__(256) void k_ntt_fwd_strided(DevCtx c, u64 *data, LimbMap map, int nl) {
+__global__ __launch_bounds__(256) void k_ntt_fwd_strided(DevCtx c, u64 *data, const u64 *src, const u64 *src2, size_t split, LimbMap map,
+                                                         int nl) {
   const int G = c.n >> R;
   const int per = G / 256;
   const size_t limb = blockIdx.x / per;
@@ -93,9 +95,10 @@ __global__ __launch_bounds__(256) void k_ntt_fwd_strided(DevCtx c, u64 *data, Li
   const Mod m = c.mods[mid];
   const NttTable t = ntt_table(c, mid);
   u64 *base = data + limb * (size_t)c.n + p;
+  const u64 *in = (limb < split ? src + limb * (size_t)c.n : src2 + (limb - split) * (size_t)c.n) + p;
   u64 x[1 << R];
 #pragma unroll
-  for (int k = 0; k < (1 << R); k++) x[k] = base[(size_t)k * G];
+  for (int k = 0; k < (1 << R); k++) x[k] = in[(size_t)k * G];
 #pragma unroll
   for (int u = 0; u < R; u++) {
     const int half = 1 << (R - 1 - u);
@@ -150,7 +153,8 @@ __global__ __launch_bounds__(256) void k_ntt_inv_strided(DevCtx c, u64 *data, Li
 // (R <= 4 stages from a canonical input stay below 4.1 q even for 50-bit primes).  Inverse: raw doubles in, re-centred,
 // R stages, N^-1, canonical u64 out.
 template <int R>
-__global__ __launch_bounds__(256) void k_ntt_fwd_strided_fp(DevCtx c, u64 *data, LimbMap map, int nl) {
+__global__ __launch_bounds__(256) void k_ntt_fwd_strided_fp(DevCtx c, u64 *data, const u64 *src, const u64 *src2, size_t split, LimbMap map,
+                                                            int nl) {
   const int G = c.n >> R;
   const int per = G / 256;
   const size_t limb = blockIdx.x / per;
@@ -159,9 +163,10 @@ __global__ __launch_bounds__(256) void k_ntt_fwd_strided_fp(DevCtx c, u64 *data,
   const Mod m = mod_at(c, mid);
   const FpTable t = fp_table(c, mid);
   u64 *base = data + limb * (size_t)c.n + p;
+  const u64 *in = (limb < split ? src + limb * (size_t)c.n : src2 + (limb - split) * (size_t)c.n) + p;
   double x[1 << R];
 #pragma unroll
-  for (int k = 0; k < (1 << R); k++) x[k] = fp_from_u64(base[(size_t)k * G]);
+  for (int k = 0; k < (1 << R); k++) x[k] = fp_from_u64(in[(size_t)k * G]);
 #pragma unroll
   for (int u = 0; u < R; u++) {
     const int half = 1 << (R - 1 - u);
@@ -241,14 +246,17 @@ static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size
 }
 
 template <int R>
-static int launch_strided(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd) {
+static int launch_strided(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd, const u64 *src = nullptr,
+                          const u64 *src2 = nullptr) {
   const int G = c->n >> R;
   dim3 grid((unsigned)(total_limbs * (G / 256))), block(256);
   const bool fp = all_limbs_fp(c, map, nl);
+  if (!src) src = d;
+  const size_t split = src2 ? total_limbs / 2 : total_limbs;
   if (fwd && fp)
-    hipLaunchKernelGGL(k_ntt_fwd_strided_fp<R>, grid, block, 0, c->stream, c->dc, d, map, nl);
+    hipLaunchKernelGGL(k_ntt_fwd_strided_fp<R>, grid, block, 0, c->stream, c->dc, d, src, src2, split, map, nl);
   else if (fwd)
-    hipLaunchKernelGGL(k_ntt_fwd_strided<R>, grid, block, 0, c->stream, c->dc, d, map, nl);
+    hipLaunchKernelGGL(k_ntt_fwd_strided<R>, grid, block, 0, c->stream, c->dc, d, src, src2, split, map, nl);
   else if (fp)
     hipLaunchKernelGGL(k_ntt_inv_strided_fp<R>, grid, block, 0, c->stream, c->dc, d, map, nl);
   else
@@ -258,7 +266,7 @@ static int launch_strided(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, si
 }
 
 // src != nullptr (forward only): read the coefficients from src, write the transform to d (saves a copy where the
-// operand must survive); rings that need the strided pre-pass copy first.
+// operand must survive); with a strided pre-pass it is that pass which reads src and writes d.
 static int copy_sources(abc_hip_ctx *c, u64 *d, const u64 *src, const u64 *src2, size_t total_limbs) {
   const size_t first = src2 ? total_limbs / 2 : total_limbs;
   ABC_HIP_CHECK(hipMemcpyAsync(d, src, first * (size_t)c->n * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -270,7 +278,7 @@ static int copy_sources(abc_hip_ctx *c, u64 *d, const u64 *src, const u64 *src2,
 static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd, const u64 *src = nullptr,
                       const u64 *src2 = nullptr) {
   if (total_limbs == 0) return 0;
-  if (src && (c->logn > 14 || !fwd)) {
+  if (src && !fwd) {
     if (copy_sources(c, d, src, src2, total_limbs)) return 1;
     src = src2 = nullptr;
   }
@@ -285,12 +293,8 @@ static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t
       // 1024-point blocks, the N > 2^14 machinery), trading an HBM round trip nobody misses at this size
       const size_t few = c->sw.few_limbs;
       if (total_limbs > few) return launch_block<14>(c, d, map, nl, total_limbs, 0, fwd, src, src2);
-      if (src) {
-        if (copy_sources(c, d, src, src2, total_limbs)) return 1;
-        src = src2 = nullptr;
-      }
       if (fwd) {
-        if (int rc = launch_strided<4>(c, d, map, nl, total_limbs, true)) return rc;
+        if (int rc = launch_strided<4>(c, d, map, nl, total_limbs, true, src, src2)) return rc;
         return launch_block<10>(c, d, map, nl, total_limbs, 4, true);
       }
       if (int rc = launch_block<10>(c, d, map, nl, total_limbs, 4, false)) return rc;
@@ -300,8 +304,8 @@ static int launch_ntt(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t
     case 16: {
       const int S0 = c->logn - kBigBlockLB;
       if (fwd) {
-        int rc = (S0 == 3) ? launch_strided<3>(c, d, map, nl, total_limbs, true)
-                           : launch_strided<4>(c, d, map, nl, total_limbs, true);
+        int rc = (S0 == 3) ? launch_strided<3>(c, d, map, nl, total_limbs, true, src, src2)
+                           : launch_strided<4>(c, d, map, nl, total_limbs, true, src, src2);
         if (rc) return rc;
         return launch_block<kBigBlockLB>(c, d, map, nl, total_limbs, S0, true);
       } else {

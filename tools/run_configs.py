@@ -135,8 +135,8 @@ def config4(dev, rank, world, batch):
 def config5(dev, rank, world, batch):
     """BFV N=2^16: depth-8 multiply chain."""
     n = 65536
-    bits = int(os.environ.get("ABC_CONFIG5_BITS", "55"))  # 50: the same depth on a chain the fp64 kernels take
-    primes = capi.create_primes(n, [bits] * 8 + [bits + 1 if bits > 50 else bits])
+    bits = int(os.environ.get("ABC_CONFIG5_BITS", "55"))  # <= 50: the same depth on a chain the fp64 kernels take
+    primes = capi.create_primes(n, [bits] * 8 + [bits + 1])
     t = capi.plain_modulus_batching(n, 20)
     g = capi.Context(capi.BFV, n, primes, t, device=dev)
     g.keygen(0xABC00001)
