@@ -201,6 +201,8 @@ int launch_ks_expand_ntt_fp(abc_hip_ctx *c, const u64 *tcoef, size_t tstride, u6
 int launch_ntt_fwd_from2(abc_hip_ctx *c, const u64 *src, const u64 *src2, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
 int launch_ntt_fwd_from(abc_hip_ctx *c, const u64 *src, u64 *d, const LimbMap &map, int nl, size_t total_limbs);  // out of place
 int launch_ntt_inv(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
+int launch_ntt_inv_strided_part(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
+int big_block_log(void);
 
 int launch_addsub(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t polys, int op);  // 0 add 1 sub 2 neg
 int launch_ckks_tensor(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, int nl, size_t count);
@@ -240,6 +242,9 @@ int gsplit_chunk15(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int 
 void gsplit_front14(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb, size_t opa_stride,
                     double *hinv, double *part, u32 gelt);
 bool bsplit_applies(const abc_hip_ctx *c, int nl);
+bool bsplit_big_applies(const abc_hip_ctx *c, int nl);
+int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count, const u64 *addend,
+               size_t addend_stride, bool add_c1);
 int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
                   size_t addend_stride, int add_c1, u64 *out);
 // integer twins of the split kernels (abc_kernels_isplit.hip)

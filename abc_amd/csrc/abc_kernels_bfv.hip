@@ -339,6 +339,79 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_bfv_tensor_intt(DevCtx c, co
   }
 }
 
+// The same fusion for N = 2^15 / 2^16, where a limb is 2^S0 blocks of 2^LB points behind a strided pass: workgroup
+// (ct, comp, limb, block) forms its block of the product and runs the block stages of the inverse transform; the strided pass
+// (launch_ntt_inv_strided_part) finishes.  Replaces k_tensor_map + the block kernel of launch_ntt_inv: 3 limb transfers per
+// product limb fewer.
+template <int LB, bool FP>
+__global__ __launch_bounds__((1 << LB) / 16) void k_bfv_tensor_inv_block(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b,
+                                                                         u64 *__restrict__ d, LimbMap map, int nlm, int S0) {
+  __shared__ u64 lds_raw[lds_words(LB)];
+  const size_t N = (size_t)c.n, pw = (size_t)nlm * N;
+  const int blk = blockIdx.x & ((1 << S0) - 1);
+  const unsigned w = blockIdx.x >> S0;
+  const int limb = w % nlm;
+  const int comp = (w / nlm) % 3;
+  const size_t ct = w / (3 * (size_t)nlm);
+  const int mid = map.id[limb];
+  const Mod m = mod_at(c, mid);
+  const size_t boff = (size_t)limb * N + ((size_t)blk << LB);
+  const u64 *__restrict__ a0 = a + ct * 2 * pw + boff, *__restrict__ a1 = a0 + pw;
+  const u64 *__restrict__ b0 = b + ct * 2 * pw + boff, *__restrict__ b1 = b0 + pw;
+  u64 *__restrict__ o = d + (ct * 3 + comp) * pw + boff;
+  if constexpr (FP) {
+    double *lds = reinterpret_cast<double *>(lds_raw);
+    const FpTable t = fp_table(c, mid);
+    const double q = m.qd, qinv = m.qinv;
+    auto st = [&](int, int i, double v) { reinterpret_cast<double *>(o)[i] = v; };  // raw doubles: the strided pass re-centres
+    auto prod = [&](double x, double y) {
+      const double h = x * y, l = __builtin_fma(x, y, -h);
+      return __builtin_fma(-__builtin_rint(h * qinv), q, h) + l;
+    };
+    if (comp == 0)
+      ntt_inv_block_a<LB, FpArith>(lds, [&](int, int i) { return prod(fp_from_u64(a0[i]), fp_from_u64(b0[i])); }, st, t, m, S0, blk);
+    else if (comp == 2)
+      ntt_inv_block_a<LB, FpArith>(lds, [&](int, int i) { return prod(fp_from_u64(a1[i]), fp_from_u64(b1[i])); }, st, t, m, S0, blk);
+    else
+      ntt_inv_block_a<LB, FpArith>(
+          lds,
+          [&](int, int i) {
+            return fp_centre(prod(fp_from_u64(a0[i]), fp_from_u64(b1[i])) + prod(fp_from_u64(a1[i]), fp_from_u64(b0[i])), q, qinv);
+          },
+          st, t, m, S0, blk);
+  } else {
+    const NttTable t = ntt_table(c, mid);
+    auto st = [&](int, int i, u64 v) { o[i] = v; };  // [0, 2q): the strided pass continues from there
+    if (comp == 0)
+      ntt_inv_block<LB>(lds_raw, [&](int, int i) { return mul_mod(a0[i], b0[i], m); }, st, t, m, S0, blk);
+    else if (comp == 2)
+      ntt_inv_block<LB>(lds_raw, [&](int, int i) { return mul_mod(a1[i], b1[i], m); }, st, t, m, S0, blk);
+    else
+      ntt_inv_block<LB>(
+          lds_raw,
+          [&](int, int i) {
+            U128 acc = mul_wide(a0[i], b1[i]);
+            mac128(acc, a1[i], b0[i]);
+            return barrett_reduce(acc, m);
+          },
+          st, t, m, S0, blk);
+  }
+}
+// 0 done, -1 not applicable, 1 error
+static int tensor_inv_big(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d, const LimbMap &map, int nlm, size_t count) {
+  if ((c->logn != 15 && c->logn != 16) || c->sw.no_tensor_intt || big_block_log() != 12) return -1;
+  bool fp = c->use_fp;
+  for (int j = 0; j < nlm; j++) fp = fp && fp_ok(c->h_mods[map.id[j]].bits);
+  const int S0 = c->logn - 12;
+  const dim3 grid((unsigned)((count * 3 * nlm) << S0)), block((1 << 12) / 16);
+  if (fp)
+    hipLaunchKernelGGL((k_bfv_tensor_inv_block<12, true>), grid, block, 0, c->stream, c->dc, a, b, d, map, nlm, S0);
+  else
+    hipLaunchKernelGGL((k_bfv_tensor_inv_block<12, false>), grid, block, 0, c->stream, c->dc, a, b, d, map, nlm, S0);
+  ABC_HIP_CHECK(hipGetLastError());
+  return launch_ntt_inv_strided_part(c, d, map, nlm, count * 3 * nlm);
+}
+
 template <int LB>
 static int launch_tensor_intt(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d, const LimbMap &map, int nlm, size_t count) {
   bool fp = c->use_fp;
@@ -426,6 +499,7 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
     if (launch_ntt_fwd_from2(c, pa, pb, aq, qmap, L, cc * 4 * L)) return 1;
     if (launch_ntt_fwd(c, aB, bmap, nBsk, cc * 4 * nBsk)) return 1;    // aB and bB are adjacent
     int rq = tensor_intt(c, aq, bq, dq, qmap, L, cc);
+    if (rq < 0) rq = tensor_inv_big(c, aq, bq, dq, qmap, L, cc);
     if (rq > 0) return 1;
     if (rq < 0) {
       hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * L * N, 256)), dim3(256), 0, c->stream, c->dc, aq, bq, dq, qmap, L, cc);
@@ -433,6 +507,7 @@ int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t c
       if (launch_ntt_inv(c, dq, qmap, L, cc * 3 * L)) return 1;
     }
     int rb = tensor_intt(c, aB, bB, dB, bmap, nBsk, cc);
+    if (rb < 0) rb = tensor_inv_big(c, aB, bB, dB, bmap, nBsk, cc);
     if (rb > 0) return 1;
     if (rb < 0) {
       hipLaunchKernelGGL(k_tensor_map, dim3(grid_for(cc * nBsk * N, 256)), dim3(256), 0, c->stream, c->dc, aB, bB, dB, bmap, nBsk,

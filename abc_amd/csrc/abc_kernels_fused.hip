@@ -1846,6 +1846,10 @@ int keyswitch_fused(abc_hip_ctx *c, const u64 *target, size_t target_stride, con
     if (!count) return 0;
     return run_gsplit15(c, 1, target, addend, target_stride, addend_stride, add_c1, key, out, nl, count, 0u);
   }
+  if (bsplit_big_applies(c, nl)) {  // BFV, N = 2^15 / 2^16, fp64-capable chain
+    if (!count) return 0;
+    return bsplit_big(c, target, target_stride, key, out, nl, count, addend, addend_stride, add_c1);
+  }
   if (c->logn > 14) return -1;
   if (c->sw.no_fused) return -1;
   if (!count) return 0;

@@ -523,4 +523,158 @@ int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
   return 0;
 }
 
+
+// ---- BFV, N = 2^15 / 2^16 (coefficient-form ciphertexts, every key prime below 2^50): the same three steps with NB = 32 / 64 ----
+// B1 k_bsplit_pass0   (ct, J, key prime I, quarter): digit J of the operand, read as it lies (no reduction modulo q_I is needed in
+//                     fp64), forward cross pass modulo q_I -> half-done limb (ct, I, J)
+// B2 k_gsplit_special<LOGN, NL, true>: tails + inner product + inverse tails, every key prime
+// B3 k_bsplit_tcoef   : special limb back to canonical coefficients (+ q_sp/2) -- once per (ct, comp), where the N = 2^14 finish
+//                     kernel recomputes it per data prime from registers (16 values; here it would be 64)
+// B4 k_bsplit_finish_big: inverse cross pass of data limb I, N^-1, subtract, q_sp^-1, addend -> coefficient form
+// Replaces, for these rings, k_ks_expand_strided_fp + block transforms + k_ks_inner + transforms + k_ks_tmod + k_ks_finish.
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_bsplit_pass0(DevCtx c, const u64 *__restrict__ src, size_t src_stride, double *__restrict__ part,
+                                                      int nl) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
+  const unsigned w = blockIdx.x >> 2;
+  const int I = (int)(w % (unsigned)(nl + 1));
+  const int J = (int)((w / (unsigned)(nl + 1)) % (unsigned)nl);
+  const size_t ct = (size_t)(w / (unsigned)(nl + 1) / (unsigned)nl);
+  const size_t N = (size_t)1 << LOGN, PS = (size_t)c.ps;
+  const int ki = (I == nl) ? c.K - 1 : I;
+  const Mod m = mod_at(c, ki);
+  const FpTable t = fp_table(c, ki);
+  const FpK kk = FpArith::consts(m);
+  const u64 *__restrict__ sp = src + ct * src_stride + (size_t)J * N;
+  double x[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) x[k] = fp_from_u64(sp[(k << 10) + p]);
+  fwd_cross<LOGNB>(x, t, kk);
+  double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + J) * PS;
+#pragma unroll
+  for (int k = 0; k < NB; k++) dst[(k << 10) + p] = x[k];
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_bsplit_tcoef(DevCtx c, const double *__restrict__ half, double *__restrict__ tco, int nl) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
+  const size_t cc = blockIdx.x >> 2;  // ct*2 + comp
+  const size_t ct = cc >> 1;
+  const int comp = (int)(cc & 1);
+  const size_t PS = (size_t)c.ps;
+  const Mod ms = mod_at(c, c.K - 1);
+  const FpTable ts = fp_table(c, c.K - 1);
+  const FpK ks = FpArith::consts(ms);
+  const double *__restrict__ src = half + ((ct * (nl + 1) + nl) * 2 + comp) * PS;
+  double t[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) t[k] = fp_centre(src[(k << 10) + p], ks.q, ks.qinv);
+  inv_cross<LOGNB>(t, ts, ks);
+  const double hq = (double)(ms.q >> 1);
+  double *__restrict__ dst = tco + cc * PS;
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const double w = fp_centre(fp_mul_lazy(t[k], ms.inv_n_c, ms.inv_n_cq, ms.qd) + hq, ms.qd, ms.qinv);
+    dst[(k << 10) + p] = w < 0.0 ? w + ms.qd : w;  // canonical [0, q_sp)
+  }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_bsplit_finish_big(DevCtx c, const double *__restrict__ half, const double *__restrict__ tco,
+                                                           const u64 *__restrict__ addend, size_t addend_stride, int add_c1,
+                                                           u64 *__restrict__ out, int nl) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
+  const int I = (int)((blockIdx.x >> 2) % (unsigned)nl);
+  const size_t cc = (size_t)((blockIdx.x >> 2) / (unsigned)nl);  // ct*2 + comp
+  const size_t ct = cc >> 1;
+  const int comp = (int)(cc & 1);
+  const size_t N = (size_t)1 << LOGN, PS = (size_t)c.ps;
+  const Mod m = mod_at(c, I);
+  const FpTable tb = fp_table(c, I);
+  const FpK kk = FpArith::consts(m);
+  double x[NB];
+  {
+    const double *__restrict__ src = half + ((ct * (nl + 1) + I) * 2 + comp) * PS;
+#pragma unroll
+    for (int k = 0; k < NB; k++) x[k] = fp_centre(src[(k << 10) + p], kk.q, kk.qinv);
+    inv_cross<LOGNB>(x, tb, kk);
+  }
+  const u64 hm = reduce64(c.mods[c.K - 1].q >> 1, m);
+  const double fix = hm ? (double)(m.q - hm) : 0.0;
+  const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
+  const double inv = cst->inv_special_c[I], inv_q = cst->inv_special_cq[I];
+  const double *__restrict__ tsrc = tco + cc * PS;
+  u64 *__restrict__ o = out + (cc * nl + I) * N;
+  const bool add = addend && (comp == 0 || add_c1);
+  const u64 *__restrict__ cin = add ? addend + ct * addend_stride + ((size_t)comp * nl + I) * N : nullptr;
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const double d = fp_mul_lazy(x[k], m.inv_n_c, m.inv_n_cq, m.qd) - (tsrc[(k << 10) + p] + fix);
+    double r = fp_mul_lazy(d, inv, inv_q, m.qd);
+    if (add) r += fp_from_u64(cin[(k << 10) + p]);
+    o[(k << 10) + p] = fp_to_canon(r, m.qd, m.qinv);
+  }
+}
+
+bool bsplit_big_applies(const abc_hip_ctx *c, int nl) {
+  if ((c->logn != 15 && c->logn != 16) || c->scheme != 1 || !c->use_fp || c->sw.no_bsplit || c->sw.no_gsplit || nl < 1 || nl > 8) return false;
+  for (int j = 0; j < c->K; j++)
+    if (!fp_ok(c->h_mods[j].bits)) return false;
+  return true;
+}
+
+template <int LOGN>
+static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, size_t cc, int nl, const u64 *target, size_t target_stride,
+                            const u64 *key, const u64 *addend, size_t addend_stride, int add_c1, u64 *out) {
+  constexpr int NB = 1 << (LOGN - 10);
+  const size_t PS = (size_t)c->dc.ps;
+  double *part = scratch, *half = part + cc * (size_t)nl * (nl + 1) * PS, *tco = half + cc * 2 * (size_t)(nl + 1) * PS;
+  hipLaunchKernelGGL((k_bsplit_pass0<LOGN>), dim3((unsigned)(cc * nl * (nl + 1) * 4)), dim3(256), 0, st, c->dc, target, target_stride, part,
+                     nl);
+  const dim3 g((unsigned)(cc * (nl + 1) * NB));
+  const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
+#define ABC_BSPB(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half)
+  switch (nl) {
+    case 1: ABC_BSPB(1); break;
+    case 2: ABC_BSPB(2); break;
+    case 3: ABC_BSPB(3); break;
+    case 4: ABC_BSPB(4); break;
+    case 5: ABC_BSPB(5); break;
+    case 6: ABC_BSPB(6); break;
+    case 7: ABC_BSPB(7); break;
+    default: ABC_BSPB(8); break;
+  }
+#undef ABC_BSPB
+  hipLaunchKernelGGL((k_bsplit_tcoef<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, half, tco, nl);
+  hipLaunchKernelGGL((k_bsplit_finish_big<LOGN>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
+                     addend_stride, add_c1, out, nl);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
+// whole call: chunks of at most 1 GiB of scratch on the context's stream (a chunk at these sizes fills the device by itself)
+int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count, const u64 *addend,
+               size_t addend_stride, bool add_c1) {
+  const size_t N = (size_t)c->n, PS = (size_t)c->dc.ps;
+  const size_t per_ct = ((size_t)nl * (nl + 1) + 2 * (size_t)(nl + 1) + 2) * PS;  // part | half | tco (words)
+  size_t chunk = (((size_t)1 << 30) / 8) / per_ct;
+  if (chunk < 1) chunk = 1;
+  if (chunk > count) chunk = count;
+  if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t cc = (count - off < chunk) ? count - off : chunk;
+    const u64 *tg = target + off * target_stride;
+    const u64 *ad = addend ? addend + off * addend_stride : nullptr;
+    u64 *o = out + off * 2 * (size_t)nl * N;
+    const int rc = (c->logn == 15)
+                       ? bsplit_big_chunk<15>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o)
+                       : bsplit_big_chunk<16>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 }  // namespace abc

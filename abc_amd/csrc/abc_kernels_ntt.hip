@@ -373,6 +373,15 @@ int launch_ks_expand_ntt_fp(abc_hip_ctx *c, const u64 *tcoef, size_t tstride, u6
   return launch_block<kBigBlockLB>(c, dec, map, nl + 1, limbs, S0, true);
 }
 
+// N > 2^14: only the strided last stages of the inverse transform (+ N^-1); the block stages were done by a kernel that fused
+// them with its own load (abc_kernels_bfv.hip, k_bfv_tensor_inv_block)
+int launch_ntt_inv_strided_part(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
+  if (c->logn != 15 && c->logn != 16) { set_error("strided inverse part: N = 2^15 / 2^16 only"); return 1; }
+  return (c->logn - kBigBlockLB == 3) ? launch_strided<3>(c, d, map, nl, total_limbs, false)
+                                      : launch_strided<4>(c, d, map, nl, total_limbs, false);
+}
+int big_block_log(void) { return kBigBlockLB; }
+
 int launch_ntt_fwd(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
   return launch_ntt(c, d, map, nl, total_limbs, true);
 }

@@ -105,6 +105,32 @@ def test_config5_bfv_depth8_chain(oracle_mod, capi):
     assert o.noise_budget(acc) > 0
 
 
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("n,bits", [(32768, [49] * 4 + [50]), (65536, [49] * 8 + [50])])
+def test_big_ring_bfv_on_an_fp64_chain(n, bits, generic, oracle_mod, capi, monkeypatch):
+    """BFV at N = 2^15 / 2^16 with every prime below 2^50 (config 5's alternative chain): the key switch takes the split
+    kernels with a radix-32 / radix-64 cross pass (abc_kernels_gsplit.hip, k_bsplit_*); with ABC_HIP_NO_BSPLIT the generic
+    sequence.  Both must give the oracle's residues."""
+    if generic:
+        monkeypatch.setenv("ABC_HIP_NO_BSPLIT", "1")
+    primes = oracle_mod.create_primes(n, bits)
+    t = oracle_mod.plain_modulus_batching(n, 20)
+    o, g = _pair(oracle_mod, capi, oracle_mod.BFV, n, primes, t, seed=77)
+    a = o.encrypt(o.encode(oracle_mod.expand_vector([3, 1, 4, 1, 5, 9, 2, 6], n)), 1)
+    b = o.encrypt(o.encode(oracle_mod.expand_vector([2, 7, 1, 8, 2, 8, 1, 8], n)), 2)
+    r = g.mul_relin(a, b)
+    _eq("N=%d fp64-chain mul_relin" % n, r, o.mul_relin(a, b))
+    assert list(o.decode(o.decrypt(r))[:8]) == [6, 7, 4, 8, 10, 72, 2, 48]
+    _eq("N=%d fp64-chain rotate" % n, g.rotate(a, 5), o.rotate(a, 5))
+    _eq("N=%d fp64-chain rotate -1" % n, g.rotate(r, -1), o.rotate(r, -1))
+    # a batch of 3 (different rows) through the same path, in place on the first operand
+    batch_a, batch_b = np.stack([a, b, r]), np.stack([b, r, a])
+    want = np.stack([o.mul_relin(x, y) for x, y in zip(batch_a[:2], batch_b[:2])])
+    got = g.mul_relin(batch_a, batch_b)
+    _eq("N=%d fp64-chain batch rows 0-1" % n, got[:2], want)
+    assert np.array_equal(got[2], g.mul_relin(r, a))
+
+
 def test_bfv_default_8192_and_16384(oracle_mod, capi):
     """The reference factory's default ring is 16384 slots (SealCiphertextFactory.h:16): 8 data limbs + special."""
     for n in (8192, 16384):
