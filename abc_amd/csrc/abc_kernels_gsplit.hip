@@ -155,14 +155,28 @@ __global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__
 //   [ct][I][comp] limbs -- k_bsplit_finish does the rest.
 template <int LOGN, int NL, bool ALL>
 __global__ __launch_bounds__(NL * 64) void k_gsplit_special(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
-                                                            double *__restrict__ tsp_half) {
+                                                            double *__restrict__ tsp_half, int cc) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, nl = NL;
   extern __shared__ double dyn[];
   const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const int blk = blockIdx.x & (NB - 1);
-  const int I = ALL ? (int)((blockIdx.x >> LOGNB) % (unsigned)(nl + 1)) : nl;
-  const size_t ct = ALL ? (size_t)((blockIdx.x >> LOGNB) / (unsigned)(nl + 1)) : (size_t)(blockIdx.x >> LOGNB);
+  // ALL: workgroup order (group of 8 key slices, ciphertext, slice within the group).  A key slice = (key prime I, block):
+  // 2 nl KiB-blocks of the key that every ciphertext multiplies with.  blockIdx mod 8 picks the XCD, so one slice always meets
+  // the same L2, and the cc workgroups that use it follow each other there: the slice is fetched once per call instead of once
+  // per ciphertext (with (ct, I, block) order 18 slices of 128 KiB per XCD competed with the streaming operands at L = 8, and
+  // 40 % of the key reads went past L2: tools/pmc_bfv.sh).
+  unsigned slice, ctu;
+  if (ALL) {
+    const unsigned sx = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    ctu = rest % (unsigned)cc;
+    slice = (rest / (unsigned)cc) * 8 + sx;
+  } else {
+    slice = (unsigned)nl * NB + (blockIdx.x & (NB - 1));
+    ctu = blockIdx.x >> LOGNB;
+  }
+  const int blk = (int)(slice & (NB - 1));
+  const int I = (int)(slice >> LOGNB);
+  const size_t ct = (size_t)ctu;
   const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps;
   const int ki = (I == nl) ? c.K - 1 : I;
   const Mod m = mod_at(c, ki);
@@ -397,7 +411,7 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
   const dim3 gsp((unsigned)(cc * NB)), gmain((unsigned)(cc * nl * NB));
 #define ABC_GSP(NLV)                                                                                                                    \
-  hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp);                            \
+  hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp, (int)cc);                            \
   hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp, tpart, nl);                     \
   if (mode == 0)                                                                                                                        \
     hipLaunchKernelGGL((k_gsplit_main<LOGN, 0, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,  \
@@ -505,7 +519,7 @@ int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
                   size_t addend_stride, int add_c1, u64 *out) {
   const dim3 g((unsigned)(cc * (nl + 1) * 16));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
-#define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<14, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half)
+#define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<14, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
   switch (nl) {
     case 1: ABC_BSP(1); break;
     case 2: ABC_BSP(2); break;
@@ -636,7 +650,7 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
                      nl);
   const dim3 g((unsigned)(cc * (nl + 1) * NB));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
-#define ABC_BSPB(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half)
+#define ABC_BSPB(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
   switch (nl) {
     case 1: ABC_BSPB(1); break;
     case 2: ABC_BSPB(2); break;
