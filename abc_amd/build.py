@@ -23,13 +23,18 @@ def _headers():
     return hs
 
 
+# probe kernels of tools/microbench.py (DESIGN.md section 4's issue-rate measurements): off in the product library
+MICROBENCH = bool(os.environ.get("ABC_HIP_WITH_MICROBENCH"))
+
+
 def _compile(src):
-    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+    probe = MICROBENCH and src == "abc_microbench.hip"
+    obj = os.path.join(OBJDIR, src.replace(".hip", ".probes.o" if probe else ".o"))
     srcp = os.path.join(CSRC, src)
     newest = max(os.path.getmtime(p) for p in [srcp] + _headers())
     if os.path.exists(obj) and os.path.getmtime(obj) > newest:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", srcp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + (["-DABC_HIP_WITH_MICROBENCH"] if probe else []) + ["-c", srcp, "-o", obj]
     subprocess.check_call(cmd)
     return obj, True
 
@@ -39,14 +44,21 @@ def build(verbose=False):
     with ThreadPoolExecutor(max_workers=6) as ex:
         results = list(ex.map(_compile, _sources()))
     objs = [o for o, _ in results]
-    if any(changed for _, changed in results) or not os.path.exists(LIB):
+    stamp = os.path.join(OBJDIR, "linked_with_probes" if MICROBENCH else "linked_without_probes")
+    if any(changed for _, changed in results) or not os.path.exists(LIB) or not os.path.exists(stamp):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         subprocess.check_call(cmd)
+        for f in ("linked_with_probes", "linked_without_probes"):
+            if os.path.exists(os.path.join(OBJDIR, f)):
+                os.remove(os.path.join(OBJDIR, f))
+        open(stamp, "w").close()
         if verbose:
             print("linked", LIB)
     return LIB
 
 
 if __name__ == "__main__":
+    if "--microbench" in sys.argv:
+        MICROBENCH = True
     build(verbose=True)
     sys.exit(0)

@@ -3,6 +3,9 @@
 // which modular-multiplication scheme the hot kernels use (DESIGN.md "Arithmetic roofline").
 #include "abc_context.hpp"
 
+// Probe kernels, not product: compiled only with -DABC_HIP_WITH_MICROBENCH (python -m abc_amd.build --microbench, which
+// tools/microbench.py asks for).  The default library keeps the entry point and answers that it was built without them.
+#ifdef ABC_HIP_WITH_MICROBENCH
 namespace abc {
 
 // 4 independent dependent-chains per lane so the result measures throughput, not latency.
@@ -505,3 +508,11 @@ int microbench_ntt(abc_hip_ctx *c, int which, int iters, double *ms) {
   return 0;
 }
 }  // namespace abc
+#else
+namespace abc {
+int microbench(abc_hip_ctx *, int, int, double *) {
+  set_error("this libabc_hip.so was built without the probe kernels (python -m abc_amd.build --microbench)");
+  return 1;
+}
+}  // namespace abc
+#endif

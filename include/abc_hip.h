@@ -168,7 +168,8 @@ int abc_hip_ntt_inverse(abc_hip_ctx *ctx, uint64_t *d_data, int mod_kind, int in
 int abc_hip_ntt_limbs(abc_hip_ctx *ctx, uint64_t *d_data, int nl, size_t polys, int inverse);
 /* key-switch contribution only: d_target [count][nl][N] -> d_out2 [count][2][nl][N]; key_kind 0 relin, else Galois elt */
 int abc_hip_keyswitch(abc_hip_ctx *ctx, const uint64_t *d_target, uint32_t key_kind, uint64_t *d_out2, int nl, size_t count);
-/* micro-benchmarks of the integer / fp64 pipes (returns elapsed ms for `iters` dependent modmuls per lane) */
+/* micro-benchmarks of the integer / fp64 pipes (returns elapsed ms for `iters` dependent modmuls per lane); probe kernels,
+ * present only in a library built with -DABC_HIP_WITH_MICROBENCH (python -m abc_amd.build --microbench), an error otherwise */
 int abc_hip_microbench(abc_hip_ctx *ctx, int which, int iters, double *ms_out);
 /* elapsed milliseconds between two HIP events recorded on the context stream */
 int abc_hip_timer_start(abc_hip_ctx *ctx);

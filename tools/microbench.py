@@ -1,4 +1,5 @@
-"""Issue-rate probes of the integer-multiply and fp64 pipes (abc_hip_microbench)."""
+"""Issue-rate probes of the integer-multiply and fp64 pipes (abc_hip_microbench).
+Needs a library with the probe kernels: `python -m abc_amd.build --microbench` (the default build leaves them out)."""
 import json
 import os
 import sys
