@@ -152,9 +152,12 @@ def measured_traffic(batch):
     if the profile is absent."""
     try:
         import glob
-        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
-        with open(latest) as f:
-            return json.load(f)["hbm_bytes_per_mul_relin"] * batch
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            with open(path) as f:
+                prof = json.load(f)
+            if "hbm_bytes_per_mul_relin" in prof:  # profiles of other operations carry other keys
+                return prof["hbm_bytes_per_mul_relin"] * batch
+        return None
     except Exception:
         return None
 
