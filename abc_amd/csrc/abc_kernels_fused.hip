@@ -1746,7 +1746,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     return run_isplit(c, 1, target, addend, target_stride, addend_stride, add_c1, key, out, nl, count, gelt);
   const ChunkPlan p = plan_chunks(c, nl, count);
   const bool use2 = LB == 14 && ckks && all_fp(c) && !c->sw.no_split && !c->sw.no_split2 && nl <= 12;
-  const bool useb = LB == 14 && !ckks && !c->sw.no_split && bsplit_applies(c, nl);  // BFV: abc_kernels_gsplit.hip, k_bsplit_finish
+  const bool useb = LB == 14 && !ckks && !c->sw.no_split && bsplit_applies(c, nl);  // BFV: abc_kernels_gsplit.hip, k_bsplit_tcoef + k_bsplit_finish_big
   const size_t SN = (use2 || useb) ? (size_t)c->dc.ps : N;
   const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
@@ -1770,7 +1770,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
         hipLaunchKernelGGL((gelt ? k_fused_operand_pass0_fp<LB, true, true> : k_fused_operand_pass0_fp<LB, true, false>),
                            dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, 0,
                            gelt, use2 ? 1 : 0);
-      else if (split && cc * nl < 128)
+      else if (split && cc * nl < c->sw.pass0_target_limit)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl * (nl + 1))), dim3((1 << LB) / 16), 0, st,
                            c->dc, tg, target_stride, (double *)s.dec, nl, 1, 0u, useb ? 1 : 0);
       else if (split)

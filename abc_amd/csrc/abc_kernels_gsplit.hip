@@ -152,9 +152,9 @@ __global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__
 // ALL = false: the special prime only (CKKS: the data primes go through k_gsplit_main); output [ct][comp] limbs.
 // ALL = true (BFV, operand in coefficient form: no diagonal term, no NTT-form output): every key prime I = 0..nl, grid
 //   (ct, I, block); the inverse-transform tails of BOTH the special limb and the accumulated data limbs; output
-//   [ct][I][comp] limbs -- k_bsplit_finish does the rest.
+//   [ct][I][comp] limbs -- k_bsplit_tcoef / k_bsplit_finish_big do the rest.
 template <int LOGN, int NL, bool ALL>
-__global__ __launch_bounds__(NL * 64) void k_gsplit_special(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
+__global__ __launch_bounds__(NL * 64, (ALL && NL == 8) ? 4 : 1) void k_gsplit_special(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
                                                             double *__restrict__ tsp_half, int cc) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, nl = NL;
   extern __shared__ double dyn[];
@@ -182,6 +182,19 @@ __global__ __launch_bounds__(NL * 64) void k_gsplit_special(DevCtx c, const doub
   const Mod m = mod_at(c, ki);
   const FpTable t = fp_table(c, ki);
   const double q = m.qd, qinv = m.qinv;
+  // NL = 8 (512 threads: one coefficient pair per thread): the key words of that pair are requested BEFORE the transform, so their
+  // latency runs under it instead of being exposed after the barrier (the transform's own per-lane twiddle loads queue up behind
+  // them on the in-order vector-memory counter, which costs nothing: all of it is one burst at the start)
+  constexpr bool PREFETCH = ALL && NL == 8;
+  u64x2 pk0[PREFETCH ? NL : 1], pk1[PREFETCH ? NL : 1];
+  if constexpr (PREFETCH) {
+    const int e = 2 * (int)threadIdx.x;
+#pragma unroll
+    for (int Jx = 0; Jx < NL; Jx++) {
+      pk0[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
+      pk1[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
+    }
+  }
   {
     double *buf = dyn + J * lds_words(10);
     const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * PS + base;
@@ -195,8 +208,14 @@ __global__ __launch_bounds__(NL * 64) void k_gsplit_special(DevCtx c, const doub
 #pragma unroll
     for (int Jx = 0; Jx < NL; Jx++) {
       const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
-      const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
-      const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
+      u64x2 k0, k1;
+      if constexpr (PREFETCH) {
+        k0 = pk0[Jx];
+        k1 = pk1[Jx];
+      } else {
+        k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
+        k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
+      }
       s0[0] += g_mulmod(v.x, fp_from_u64(k0.x), q, qinv);
       s0[1] += g_mulmod(v.y, fp_from_u64(k0.y), q, qinv);
       s1[0] += g_mulmod(v.x, fp_from_u64(k1.x), q, qinv);
@@ -455,58 +474,15 @@ int gsplit_chunk15(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int 
 
 // ---- BFV (coefficient-form ciphertexts), N = 2^14: the key switch behind k_fused_operand_pass0_fp<14, false, false> ----
 // k_gsplit_special<14, NL, true> leaves, per (ct, key prime, component), the accumulated limb after stages 13..4 of its inverse
-// transform.  This kernel (registers only) finishes both the data limb I and the special limb (cross pass, N^-1; the special
-// one + q_sp/2, canonical) and forms  out = (INTT_I(acc) - (t mod q_I + fix)) q_sp^-1 (+ addend)  in coefficient form --
-// k_fused_ks_moddown_bfv_fp without its 139 KiB workgroup.
-__global__ __launch_bounds__(256) void k_bsplit_finish(DevCtx c, const double *__restrict__ half, const u64 *__restrict__ addend,
-                                                       size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl) {
-  constexpr int LOGN = 14, NB = 16;
-  const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
-  const int I = (int)((blockIdx.x >> 2) % (unsigned)nl);
-  const size_t cc = (size_t)((blockIdx.x >> 2) / (unsigned)nl);  // ct*2 + comp
-  const size_t ct = cc >> 1;
-  const int comp = (int)(cc & 1);
-  const size_t N = (size_t)1 << LOGN, PS = (size_t)c.ps;
-  double t[NB], x[NB];
-  {
-    const Mod ms = mod_at(c, c.K - 1);
-    const FpTable ts = fp_table(c, c.K - 1);
-    const FpK ks = FpArith::consts(ms);
-    const double *__restrict__ src = half + ((ct * (nl + 1) + nl) * 2 + comp) * PS;
-#pragma unroll
-    for (int k = 0; k < NB; k++) t[k] = fp_centre(src[(k << 10) + p], ks.q, ks.qinv);
-    inv_cross<4>(t, ts, ks);
-    const double hq = (double)(ms.q >> 1);
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      const double w = fp_centre(fp_mul_lazy(t[k], ms.inv_n_c, ms.inv_n_cq, ms.qd) + hq, ms.qd, ms.qinv);
-      t[k] = w < 0.0 ? w + ms.qd : w;  // canonical [0, q_sp)
-    }
-  }
-  const Mod m = mod_at(c, I);
-  const FpTable tb = fp_table(c, I);
-  const FpK kk = FpArith::consts(m);
-  {
-    const double *__restrict__ src = half + ((ct * (nl + 1) + I) * 2 + comp) * PS;
-#pragma unroll
-    for (int k = 0; k < NB; k++) x[k] = fp_centre(src[(k << 10) + p], kk.q, kk.qinv);
-    inv_cross<4>(x, tb, kk);
-  }
-  const u64 hm = reduce64(c.mods[c.K - 1].q >> 1, m);
-  const double fix = hm ? (double)(m.q - hm) : 0.0;
-  const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
-  const double inv = cst->inv_special_c[I], inv_q = cst->inv_special_cq[I];
-  u64 *__restrict__ o = out + (cc * nl + I) * N;
-  const bool add = addend && (comp == 0 || add_c1);
-  const u64 *__restrict__ cin = add ? addend + ct * addend_stride + ((size_t)comp * nl + I) * N : nullptr;
-#pragma unroll
-  for (int k = 0; k < NB; k++) {
-    const double d = fp_mul_lazy(x[k], m.inv_n_c, m.inv_n_cq, m.qd) - (t[k] + fix);
-    double r = fp_mul_lazy(d, inv, inv_q, m.qd);
-    if (add) r += fp_from_u64(cin[(k << 10) + p]);
-    o[(k << 10) + p] = fp_to_canon(r, m.qd, m.qinv);
-  }
-}
+// transform.  k_bsplit_tcoef / k_bsplit_finish_big (defined with the N = 2^15 / 2^16 sequence below; registers only) finish the
+// special limb once per (ct, component) and each data limb: cross pass, N^-1, (x - (t mod q_I + fix)) q_sp^-1 (+ addend) in
+// coefficient form -- k_fused_ks_moddown_bfv_fp without its 139 KiB workgroup.  (A single kernel that recomputed the special
+// limb's cross pass per data prime from registers was 1 - 3 % slower.)
+template <int LOGN>
+__global__ void k_bsplit_tcoef(DevCtx c, const double *__restrict__ half, double *__restrict__ tco, int nl);
+template <int LOGN>
+__global__ void k_bsplit_finish_big(DevCtx c, const double *__restrict__ half, const double *__restrict__ tco, const u64 *__restrict__ addend,
+                                    size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl);
 
 // half: [cc][nl+1][2] limbs at stride c->dc.ps; part as written by k_fused_operand_pass0_fp<14, false, false> (padded layout)
 bool bsplit_applies(const abc_hip_ctx *c, int nl) {
@@ -531,8 +507,11 @@ int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
     default: ABC_BSP(8); break;
   }
 #undef ABC_BSP
-  hipLaunchKernelGGL(k_bsplit_finish, dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, addend, addend_stride, add_c1, out,
-                     nl);
+  // half occupies the ksacc + tsp regions of the caller's scratch (2 nl + 2 limbs per ciphertext), tco the tlast region behind them
+  double *tco = half + cc * 2 * (size_t)(nl + 1) * (size_t)c->dc.ps;
+  hipLaunchKernelGGL((k_bsplit_tcoef<14>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, half, tco, nl);
+  hipLaunchKernelGGL((k_bsplit_finish_big<14>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
+                     addend_stride, add_c1, out, nl);
   ABC_HIP_CHECK(hipGetLastError());
   return 0;
 }

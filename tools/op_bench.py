@@ -49,7 +49,7 @@ def main():
     del a, b, out
     g.close()
     # ---- BFV N=2^12 (config 2) and BFVDefault(16384) ----
-    for n, B in ((4096, 1024), (16384, 64)):
+    for n, B in ((4096, 1024), (16384, 256)):
         g = capi.Context.bfv_default(n)
         g.keygen(1)
         L = g.L
