@@ -49,6 +49,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="bound of each cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-60bit", action="store_true", help="skip the 60-bit-prime (integer kernel) side measurement")
+    ap.add_argument("--no-bfv", action="store_true", help="skip the BFV default-ring side measurement")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="rehearse launch + sharding + gather with gloo on the CPU (no device work, no timing claims)")
     return ap.parse_args(argv)
@@ -328,6 +329,39 @@ def run_rank(args):
                                   o6[B60 - 1].cpu().numpy().view(np.uint64)):
                 raise SystemExit("bench: 60-bit chain result differs from the oracle")
             g60.close()
+        if world == 1 and not args.no_bfv:
+            # the reference itself is BFV on BFVDefault(16384) with Batching(N, 20) (ref:src/runtime/SealCiphertextFactory.cpp:72-100):
+            # the same operation on ITS scheme and ring, beside the CKKS headline (BEHZ multiply + relinearise, 8 data limbs)
+            gb = capi.Context.bfv_default(16384, device=local_rank)
+            gb.set_stream(stream.cuda_stream)
+            gb.keygen(0xABC00001)
+            Bb, Lb, nb = 256, gb.L, 16384
+            with torch.cuda.stream(stream):
+                def rand_bfv():
+                    t = torch.empty((Bb, 2, Lb, nb), dtype=torch.int64, device=dev)
+                    for j, q in enumerate(gb.primes[:Lb]):
+                        t[:, :, j, :] = torch.randint(0, q, (Bb, 2, nb), dtype=torch.int64, device=dev)
+                    return t
+                ab, bb = rand_bfv(), rand_bfv()
+                ob = torch.empty_like(ab)
+            pb = [C.c_void_p(t.data_ptr()) for t in (ab, bb, ob)]
+            for _ in range(2):
+                gb.op("mul_relin", *pb, Lb, C.c_size_t(Bb))
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(5):
+                gb.op("mul_relin", *pb, Lb, C.c_size_t(Bb))
+            torch.cuda.synchronize()
+            line["value_bfv_default_ring"] = {"value": 5 * Bb / (time.perf_counter() - tb), "unit": "mul+relin/s",
+                                              "workload": "BFV BFVDefault(16384) (8 data limbs + special), t = Batching(16384, 20), batch 256"}
+            ob_ = om.Oracle(om.BFV, nb, list(gb.primes), gb.t)
+            ob_.keygen(0xABC00001)
+            i = Bb - 1
+            if not np.array_equal(ob_.mul_relin(ab[i].cpu().numpy().view(np.uint64), bb[i].cpu().numpy().view(np.uint64)),
+                                  ob[i].cpu().numpy().view(np.uint64)):
+                raise SystemExit("bench: BFV default-ring result differs from the oracle")
+            del ab, bb, ob
+            gb.close()
         if not args.no_cpu and world == 1:  # CPU leg on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(primes, args.cpu_seconds)
         print(json.dumps(line), flush=True)

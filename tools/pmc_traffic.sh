@@ -8,8 +8,8 @@ tag=${1:-run}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmc_$tag
 mkdir -p $out
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o fetch --output-format csv -- python3 bench.py --batch 1024 --steps 2 --warmup 1 --no-cpu --no-60bit > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o write --output-format csv -- python3 bench.py --batch 1024 --steps 2 --warmup 1 --no-cpu --no-60bit > $out/write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o fetch --output-format csv -- python3 bench.py --batch 1024 --steps 2 --warmup 1 --no-cpu --no-60bit --no-bfv > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o write --output-format csv -- python3 bench.py --batch 1024 --steps 2 --warmup 1 --no-cpu --no-60bit --no-bfv > $out/write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/cal_fetch -o cal --output-format csv -- python3 tools/ntt_bench.py 14 4096 2 1 > $out/cal_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/cal_write -o cal --output-format csv -- python3 tools/ntt_bench.py 14 4096 2 1 > $out/cal_write.log 2>&1
 python3 tools/pmc_traffic.py $out

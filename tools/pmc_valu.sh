@@ -6,8 +6,8 @@ tag=${1:-run}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmcv_$tag
 mkdir -p $out
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d $out/insts -o insts --output-format csv -- python3 bench.py --batch 1024 --steps 2 --warmup 1 --no-cpu --no-60bit > $out/insts.log 2>&1
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d $out/busy -o busy --output-format csv -- python3 bench.py --batch 1024 --steps 2 --warmup 1 --no-cpu --no-60bit > $out/busy.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d $out/insts -o insts --output-format csv -- python3 bench.py --batch 1024 --steps 2 --warmup 1 --no-cpu --no-60bit --no-bfv > $out/insts.log 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d $out/busy -o busy --output-format csv -- python3 bench.py --batch 1024 --steps 2 --warmup 1 --no-cpu --no-60bit --no-bfv > $out/busy.log 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, json, os, sys
 out = sys.argv[1]
