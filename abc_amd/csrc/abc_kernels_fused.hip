@@ -1027,7 +1027,6 @@ static inline FusedScratch carve(u64 *base, size_t chunk, int nl, size_t N) {
 template <int LB>
 __global__ __launch_bounds__(256) void k_split3_pass_fp(DevCtx c, const double *__restrict__ tsp_half, double *__restrict__ tpart, int nl) {
   static_assert(LB == 14, "split transforms are laid out for N = 2^14");
-  const size_t N = (size_t)1 << LB;
   const size_t cc = blockIdx.x >> 2;                                  // ct*2 + comp
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;      // position inside every 1024-point block
   const int hi0[1] = {0};
@@ -1097,7 +1096,6 @@ __global__ __launch_bounds__(NL ? (NL + 1) * 64 : 832) void k_split3_main_fp(Dev
         lane);
   }
   __syncthreads();
-  const double spc = c.cst->special_c[I], spq = c.cst->special_cq[I];
   const double inv = c.cst->inv_special_c[I], inv_q = c.cst->inv_special_cq[I];
   const size_t pw = (size_t)nl * N;
   const double *tt0 = dyn + (nl - 1) * lds_words(10), *tt1 = dyn + nl * lds_words(10);
@@ -1156,11 +1154,11 @@ __global__ __launch_bounds__(NL ? (NL + 1) * 64 : 832) void k_split3_main_fp(Dev
     const f64x2 u0 = *reinterpret_cast<const f64x2 *>(tt0 + lds_pad(e)), u1 = *reinterpret_cast<const f64x2 *>(tt1 + lds_pad(e));
     // (sum + q_sp (c0, c1) - NTT(t)) q_sp^-1
     u64x2 r;
-    r.x = fp_to_canon(fp_mul_lazy(s0[0] + fp_mul_lazy(d0[0], spc, spq, q) - u0.x, inv, inv_q, q), q, qinv);
-    r.y = fp_to_canon(fp_mul_lazy(s0[1] + fp_mul_lazy(d0[1], spc, spq, q) - u0.y, inv, inv_q, q), q, qinv);
+    r.x = fp_to_canon(fp_mul_lazy(s0[0] - u0.x, inv, inv_q, q) + d0[0], q, qinv);
+    r.y = fp_to_canon(fp_mul_lazy(s0[1] - u0.y, inv, inv_q, q) + d0[1], q, qinv);
     *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 0) * nl + I) * N + base + e) = r;
-    r.x = fp_to_canon(fp_mul_lazy(s1[0] + fp_mul_lazy(d1[0], spc, spq, q) - u1.x, inv, inv_q, q), q, qinv);
-    r.y = fp_to_canon(fp_mul_lazy(s1[1] + fp_mul_lazy(d1[1], spc, spq, q) - u1.y, inv, inv_q, q), q, qinv);
+    r.x = fp_to_canon(fp_mul_lazy(s1[0] - u1.x, inv, inv_q, q) + d1[0], q, qinv);
+    r.y = fp_to_canon(fp_mul_lazy(s1[1] - u1.y, inv, inv_q, q) + d1[1], q, qinv);
     *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
   }
 }
@@ -1220,7 +1218,6 @@ __global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const doubl
   const size_t pw = (size_t)nl * N;
   // scalar loads (constant address space): a vector load of these after the transform would expose one more memory latency
   const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
-  const double spc = cst->special_c[I], spq = cst->special_cq[I];
   const double inv = cst->inv_special_c[I], inv_q = cst->inv_special_cq[I];
 
   // (1) twiddle table, (2) this wavefront's half-done limb, (3) the operands of this thread's first coefficient pair
@@ -1271,8 +1268,12 @@ __global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const doubl
   __syncthreads();
   if (has_limb) {
     double *buf = dyn + W * lds_words(10);
+    // half-done limbs arrive below 4.1 q (four lazy stages from a canonical value): primes of 49 / 50 bits re-centre before the
+    // remaining ten stages, smaller ones have the headroom for all fourteen (abc_ntt.hpp, FpK::red) -- wavefront-uniform branch
+    if (m.bits >= 49) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) xin[r] = fp_centre(xin[r], q, qinv);
+      for (int r = 0; r < 16; r++) xin[r] = fp_centre(xin[r], q, qinv);
+    }
     ntt_fwd_tail1024_pairs<FpArith>(buf, xin, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk, lane, ltw);
   }
   __syncthreads();
@@ -1320,11 +1321,11 @@ __global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const doubl
     }
     const f64x2 u0 = *reinterpret_cast<const f64x2 *>(tt0 + lds_pad(e)), u1 = *reinterpret_cast<const f64x2 *>(tt1 + lds_pad(e));
     u64x2 r;
-    r.x = fp_to_canon(fp_mul_lazy(s0[0] + fp_mul_lazy(d0[0], spc, spq, q) - u0.x, inv, inv_q, q), q, qinv);
-    r.y = fp_to_canon(fp_mul_lazy(s0[1] + fp_mul_lazy(d0[1], spc, spq, q) - u0.y, inv, inv_q, q), q, qinv);
+    r.x = fp_to_canon(fp_mul_lazy(s0[0] - u0.x, inv, inv_q, q) + d0[0], q, qinv);
+    r.y = fp_to_canon(fp_mul_lazy(s0[1] - u0.y, inv, inv_q, q) + d0[1], q, qinv);
     *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 0) * nl + I) * N + base + e) = r;
-    r.x = fp_to_canon(fp_mul_lazy(s1[0] + fp_mul_lazy(d1[0], spc, spq, q) - u1.x, inv, inv_q, q), q, qinv);
-    r.y = fp_to_canon(fp_mul_lazy(s1[1] + fp_mul_lazy(d1[1], spc, spq, q) - u1.y, inv, inv_q, q), q, qinv);
+    r.x = fp_to_canon(fp_mul_lazy(s1[0] - u1.x, inv, inv_q, q) + d1[0], q, qinv);
+    r.y = fp_to_canon(fp_mul_lazy(s1[1] - u1.y, inv, inv_q, q) + d1[1], q, qinv);
     *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
   };
   compute_pair(2 * (int)threadIdx.x, ops);

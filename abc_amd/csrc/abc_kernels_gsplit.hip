@@ -304,7 +304,6 @@ __global__ __launch_bounds__(512, 4) void k_gsplit_main(DevCtx c, const double *
   f64x2 *ltw = reinterpret_cast<f64x2 *>(dyn + (nl + 1) * lds_words(10));
   const size_t pw = (size_t)nl * N;
   const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
-  const double spc = cst->special_c[I], spq = cst->special_cq[I];
   const double inv = cst->inv_special_c[I], inv_q = cst->inv_special_cq[I];
 
   f64x2 twv[PER];
@@ -392,11 +391,11 @@ __global__ __launch_bounds__(512, 4) void k_gsplit_main(DevCtx c, const double *
   }
   const f64x2 u0 = *reinterpret_cast<const f64x2 *>(tt0 + lds_pad(e)), u1 = *reinterpret_cast<const f64x2 *>(tt1 + lds_pad(e));
   u64x2 r;
-  r.x = fp_to_canon(fp_mul_lazy(s0[0] + fp_mul_lazy(d0[0], spc, spq, q) - u0.x, inv, inv_q, q), q, qinv);
-  r.y = fp_to_canon(fp_mul_lazy(s0[1] + fp_mul_lazy(d0[1], spc, spq, q) - u0.y, inv, inv_q, q), q, qinv);
+  r.x = fp_to_canon(fp_mul_lazy(s0[0] - u0.x, inv, inv_q, q) + d0[0], q, qinv);
+  r.y = fp_to_canon(fp_mul_lazy(s0[1] - u0.y, inv, inv_q, q) + d0[1], q, qinv);
   *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 0) * nl + I) * N + base + e) = r;
-  r.x = fp_to_canon(fp_mul_lazy(s1[0] + fp_mul_lazy(d1[0], spc, spq, q) - u1.x, inv, inv_q, q), q, qinv);
-  r.y = fp_to_canon(fp_mul_lazy(s1[1] + fp_mul_lazy(d1[1], spc, spq, q) - u1.y, inv, inv_q, q), q, qinv);
+  r.x = fp_to_canon(fp_mul_lazy(s1[0] - u1.x, inv, inv_q, q) + d1[0], q, qinv);
+  r.y = fp_to_canon(fp_mul_lazy(s1[1] - u1.y, inv, inv_q, q) + d1[1], q, qinv);
   *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
 }
 
