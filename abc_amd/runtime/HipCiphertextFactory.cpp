@@ -350,6 +350,39 @@ sealwire::Compression wireMode(int compression) {
 }
 }  // namespace
 
+namespace {
+sealwire::CiphertextImage keyImage(const sealwire::ParmsId &id, size_t N, size_t K, const uint64_t *words) {
+  sealwire::CiphertextImage img;
+  img.id = id;
+  img.nttForm = true;
+  img.size = 2;
+  img.ringDegree = N;
+  img.limbs = K;
+  img.scale = 1.0;
+  img.data.assign(words, words + 2 * K * N);
+  return img;
+}
+// residues must be canonical: the device kernels take words below their prime (the fp64 ones convert them exactly only below 2^52)
+void checkReduced(const std::vector<uint64_t> &data, size_t polys, size_t N, const std::vector<uint64_t> &primes, const char *what) {
+  const size_t K = primes.size();
+  for (size_t p = 0; p < polys; ++p)
+    for (size_t j = 0; j < K; ++j) {
+      const uint64_t q = primes[j];
+      const uint64_t *w = data.data() + (p * K + j) * N;
+      for (size_t i = 0; i < N; ++i)
+        if (w[i] >= q) throw std::runtime_error(std::string(what) + ": residue not reduced modulo its prime");
+    }
+}
+void checkKeyImage(const sealwire::CiphertextImage &img, const sealwire::ParmsId &id, size_t N, const std::vector<uint64_t> &primes,
+                   const char *what) {
+  const size_t K = primes.size();
+  if (img.id != id) throw std::runtime_error(std::string(what) + ": parms_id is not this factory's key-level parameter set");
+  if (!img.nttForm || img.size != 2 || img.ringDegree != N || img.limbs != K)
+    throw std::runtime_error(std::string(what) + ": expected a size-2 NTT-form key over all key primes");
+  checkReduced(img.data, 2, N, primes, what);
+}
+}  // namespace
+
 void HipCiphertextFactory::saveCiphertext(const AbstractCiphertext &ciphertext, std::ostream &out, int compression) const {
   const auto &c = dynamic_cast<const HipCiphertext &>(ciphertext);
   if (&c.getFactory() != this) throw std::runtime_error("saveCiphertext: ciphertext belongs to another factory");
@@ -422,29 +455,12 @@ void HipCiphertextFactory::loadSecretKey(std::istream &in) {
   if (img.id != sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K))
     throw std::runtime_error("loadSecretKey: parms_id is not this factory's key-level parameter set");
   if (img.coeffCount != K * N) throw std::runtime_error("loadSecretKey: expected N coefficients per key prime (NTT form)");
+  checkReduced(img.data, 1, N, chain, "loadSecretKey");
   const int rc = abc_hip_load_secret_key(ctx, img.data.data());
   std::fill(img.data.begin(), img.data.end(), 0);
   abcHipCheck(rc, "secret key upload");
 }
 
-namespace {
-sealwire::CiphertextImage keyImage(const sealwire::ParmsId &id, size_t N, size_t K, const uint64_t *words) {
-  sealwire::CiphertextImage img;
-  img.id = id;
-  img.nttForm = true;
-  img.size = 2;
-  img.ringDegree = N;
-  img.limbs = K;
-  img.scale = 1.0;
-  img.data.assign(words, words + 2 * K * N);
-  return img;
-}
-void checkKeyImage(const sealwire::CiphertextImage &img, const sealwire::ParmsId &id, size_t N, size_t K, const char *what) {
-  if (img.id != id) throw std::runtime_error(std::string(what) + ": parms_id is not this factory's key-level parameter set");
-  if (!img.nttForm || img.size != 2 || img.ringDegree != N || img.limbs != K)
-    throw std::runtime_error(std::string(what) + ": expected a size-2 NTT-form key over all key primes");
-}
-}  // namespace
 
 void HipCiphertextFactory::savePublicKey(std::ostream &out, int compression) const {
   const size_t N = ciphertextSlotSize, K = chain.size();
@@ -457,7 +473,7 @@ void HipCiphertextFactory::loadPublicKey(std::istream &in) {
   const size_t N = ciphertextSlotSize, K = chain.size();
   sealwire::CiphertextImage img;
   sealwire::load(in, img, (uint64_t)2 * K * N);
-  checkKeyImage(img, sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K), N, K, "loadPublicKey");
+  checkKeyImage(img, sealwire::parmsId(wireParms(ckksMode, ciphertextSlotSize, chain, plainModulus), K), N, chain, "loadPublicKey");
   abcHipCheck(abc_hip_load_public_key(ctx, img.data.data()), "public key upload");
 }
 
@@ -482,7 +498,7 @@ void HipCiphertextFactory::loadRelinKeys(std::istream &in) {
   std::vector<uint64_t> words;
   words.reserve((size_t)limbs * per);
   for (const auto &pk : img.keys[0]) {
-    checkKeyImage(pk, id, N, K, "loadRelinKeys");
+    checkKeyImage(pk, id, N, chain, "loadRelinKeys");
     words.insert(words.end(), pk.data.begin(), pk.data.end());
   }
   abcHipCheck(abc_hip_load_relin_key(ctx, words.data()), "relinearisation key upload");
@@ -517,7 +533,7 @@ void HipCiphertextFactory::loadGaloisKeys(std::istream &in) {
     if (entry.size() != (size_t)limbs) throw std::runtime_error("loadGaloisKeys: expected one key per data prime");
     words.clear();
     for (const auto &pk : entry) {
-      checkKeyImage(pk, id, N, K, "loadGaloisKeys");
+      checkKeyImage(pk, id, N, chain, "loadGaloisKeys");
       words.insert(words.end(), pk.data.begin(), pk.data.end());
     }
     abcHipCheck(abc_hip_load_galois_key(ctx, (uint32_t)(2 * idx + 1), words.data()), "Galois key upload");

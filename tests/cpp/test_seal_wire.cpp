@@ -320,6 +320,14 @@ int main(int argc, char **argv) {
     small.saveSecretKey(sk);
     std::stringstream asPublic(sk.str());
     EXPECT_THROWS(small.loadPublicKey(asPublic));  // a secret-key stream is not a public key
+    // a key whose words are not reduced modulo their prime is refused (the kernels assume canonical residues)
+    std::stringstream good, bad;
+    small.saveRelinKeys(good);
+    sealwire::KSwitchImage img;
+    sealwire::load(good, img);
+    img.keys[0][1].data[7] = small.prime(0);  // first limb, = q_0
+    sealwire::save(bad, img);
+    EXPECT_THROWS(small.loadRelinKeys(bad));
   });
   t.run("batch mode: B instances, one SEAL object each", [] {
     HipCiphertextFactory f(4096, 0, 5, 3);
