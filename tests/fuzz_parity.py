@@ -87,6 +87,7 @@ def draw_case(rng, max_logn):
     case["step"] = int(rng.integers(-(n // 2) + 1, n // 2)) if rng.integers(0, 2) else int(rng.choice([1, -1, 2, 3, 7, 64, -24, n // 4]))
     if case["step"] == 0:
         case["step"] = 1
+    case["alias"] = int(rng.choice([0, 0, 1, 2]))
     case["level_draw"] = float(rng.random())
     case["data_seed"] = int(rng.integers(0, 2 ** 31))
     return case
@@ -131,7 +132,19 @@ def run_case(case, om, capi, contexts):
         got, want = g.relinearize(x), np.stack([o.relinearize(r) for r in x])
     elif op in ("mul_relin", "multiply", "add", "sub"):
         x, y = random_ct(rng, primes, nl, n, B), random_ct(rng, primes, nl, n, B)
-        got = getattr(g, op)(x, y)
+        alias = case.get("alias", 0) if op != "multiply" else 0
+        if alias:  # the C ABI allows the result to overwrite an operand: 1 = first, 2 = second
+            import ctypes as C
+            bx, by = g.upload(x), g.upload(y)
+            dst = bx if alias == 1 else by
+            if op == "mul_relin":
+                g.op(op, bx.ptr, by.ptr, dst.ptr, nl, C.c_size_t(B))
+            else:
+                g.op(op, bx.ptr, by.ptr, dst.ptr, 2, nl, C.c_size_t(B))
+            got = g.download(dst, x.shape)
+            bx.free(); by.free()
+        else:
+            got = getattr(g, op)(x, y)
         want = np.stack([getattr(o, op)(a, b) for a, b in zip(x, y)])
     elif op == "negate":
         x = random_ct(rng, primes, nl, n, B)
