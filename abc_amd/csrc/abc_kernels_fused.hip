@@ -1199,7 +1199,10 @@ template <int MODE, bool GAL, int NL>
 __global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const double *__restrict__ part,
                                                                    const double *__restrict__ tpart, const u64 *__restrict__ opa,
                                                                    const u64 *__restrict__ opb, size_t opa_stride, size_t opb_stride,
-                                                                   int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out, u32 gelt) {
+                                                                   int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out, u32 gelt,
+                                                                   u32 imap, int ni) {
+  // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all of them: 0x3210, ni = nl; a subset
+  // when a chain mixes fp64-capable and wider primes: abc_kernels_isplit.hip)
   extern __shared__ double dyn[];  // nl + 1 transform buffers, then the block's twiddle table (1024 {w, w/q} pairs)
   // 512 threads whatever nl: one coefficient pair per thread afterwards, so every operand of that phase is requested up front;
   // wavefronts nl + 1 .. 7 have no limb to transform and only take part in the table fill and the inner product
@@ -1208,8 +1211,8 @@ __global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const doubl
   const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int blk = blockIdx.x & 15;
-  const int I = (int)((blockIdx.x >> 4) % nl);
-  const size_t ct = (size_t)((blockIdx.x >> 4) / nl);
+  const int I = (int)((imap >> (4 * ((blockIdx.x >> 4) % (unsigned)ni))) & 15u);
+  const size_t ct = (size_t)((blockIdx.x >> 4) / (unsigned)ni);
   const size_t N = (size_t)c.n, base = (size_t)blk << 10;
   const Mod m = mod_at(c, I);
   const FpTable t = fp_table(c, I);
@@ -1333,13 +1336,16 @@ __global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const doubl
 
 template <int MODE, bool GAL>
 static bool launch_split4_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const double *tpart, const u64 *opa,
-                               const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt) {
+                               const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt,
+                               u32 imap = 0x3210u, int ni = -1) {
   if (nl < 1 || nl > 4) return false;
-  const dim3 grid((unsigned)(cc * nl * 16)), block(512);
+  if (ni < 0) ni = nl;
+  if (ni == 0) return true;
+  const dim3 grid((unsigned)(cc * ni * 16)), block(512);
   const size_t lds = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
 #define ABC_TM4(NLV)                                                                                                                 \
   hipLaunchKernelGGL((k_split4_main_fp<MODE, GAL, NLV>), grid, block, lds, st, c->dc, part, tpart, opa, opb, opa_stride, opb_stride, \
-                     add_c1, key, out, gelt)
+                     add_c1, key, out, gelt, imap, ni)
   switch (nl) {
     case 1: ABC_TM4(1); break;
     case 2: ABC_TM4(2); break;
@@ -1348,6 +1354,14 @@ static bool launch_split4_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   }
 #undef ABC_TM4
   return true;
+}
+// the same launch over a subset of the data primes (mixed chains, abc_kernels_isplit.hip): mode 0 multiply, mode 1 key switch
+bool split4_main_subset(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const double *part, const double *tpart, const u64 *opa,
+                        const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt, u32 imap,
+                        int ni) {
+  if (mode == 0) return launch_split4_main<0, false>(st, c, cc, nl, part, tpart, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, imap, ni);
+  if (gelt) return launch_split4_main<1, true>(st, c, cc, nl, part, tpart, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, imap, ni);
+  return launch_split4_main<1, false>(st, c, cc, nl, part, tpart, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, imap, ni);
 }
 
 

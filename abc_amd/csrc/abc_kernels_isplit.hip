@@ -8,6 +8,11 @@
 // Arithmetic notes: GUARD = a key prime above 57 bits (guarded butterflies, values < 4q); otherwise unguarded (values grow by
 // 4q per stage, < 64q after the 14 stages of register pass + tail, canonicalised once).  Inner products accumulate 128-bit
 // products of CANONICAL operands, four at a time (barrett_reduce admits 4 products of reduced operands for q < 2^61).
+// Mixed chains: the arithmetic is a property of the prime a transform runs modulo, not of the chain.  In {60,40,40,40,60} only
+// the transforms modulo the two 60-bit primes need integers; everything modulo a data prime below 2^50 -- 12 of the 20
+// decomposition transforms, 6 of the 8 mod-down transforms and three quarters of the inner products -- takes the exact-fp64
+// form of abc_kernels_fused.hip: `fpmask` (bit I = data prime I below 2^50) makes K1 and K2b write those half-done limbs as
+// doubles, and the main step is launched twice, k_split4_main_fp over the fp64 primes and k_isplit_main over the others.
 #include "abc_context.hpp"
 
 namespace abc {
@@ -28,7 +33,7 @@ __device__ __forceinline__ void block_twiddles_fetch_g(const TW *tw, int S0, int
 // K1 (key switch, KS = true): the operand limb itself (NTT form, Galois gather folded into the load) instead of a1 b1
 template <int LB, bool GUARD, bool KS, bool GAL>
 __global__ __launch_bounds__((1 << LB) / 16) void k_isplit_pass0(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b,
-                                                                 size_t a_stride, u64 *__restrict__ part, int nl, u32 gelt) {
+                                                                 size_t a_stride, u64 *__restrict__ part, int nl, u32 gelt, u32 fpmask) {
   static_assert(LB == 14, "split transforms are laid out for N = 2^14");
   __shared__ u64 lds[lds_words(LB)];
   const int j = blockIdx.x % nl;
@@ -57,6 +62,19 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_isplit_pass0(DevCtx c, const
     if (I == j) continue;
     const int ki = (I == nl) ? c.K - 1 : I;
     const Mod mI = c.mods[ki];
+    u64 *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * (size_t)c.ps;
+    if (I < nl && ((fpmask >> I) & 1u)) {  // q_I below 2^50: canonical residue modulo q_I as a double, fp64 register pass, raw doubles out
+      const Mod mf = mod_at(c, ki);
+      const FpTable tf = fp_table(c, ki);
+      const FpK kf = FpArith::consts(mf);
+      double yd[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) yd[k] = fp_from_u64(reduce64(src[k], mI));
+      fwd_pass<FpArith, LB, 0, 4>(yd, hi0, tf, kf, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 16; k++) reinterpret_cast<double *>(dst)[(k << 10) + tid] = yd[k];
+      continue;
+    }
     const NttTable t = ntt_table(c, ki);
     const typename A::K kk = A::consts(mI);
     // residues are < q_j; the guarded pass accepts inputs < 4 q_I, the unguarded one < 8 q_I (workgroup-uniform choice)
@@ -70,7 +88,6 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_isplit_pass0(DevCtx c, const
       for (int k = 0; k < 16; k++) y[k] = src[k];
     }
     fwd_pass<A, LB, 0, 4>(y, hi0, t, kk, 0, 0);
-    u64 *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * (size_t)c.ps;
 #pragma unroll
     for (int k = 0; k < 16; k++) dst[(k << 10) + tid] = y[k];
   }
@@ -129,7 +146,8 @@ __global__ __launch_bounds__(NL * 64) void k_isplit_special(DevCtx c, const u64 
 // K2b (registers only): last radix-16 pass of that inverse transform, N^-1, + q_sp/2; then per data prime the first radix-16
 // pass of the forward transform of (t mod q_j + fix)
 template <int LB, bool GUARD>
-__global__ __launch_bounds__(256) void k_isplit_pass(DevCtx c, const u64 *__restrict__ tsp_half, u64 *__restrict__ tpart, int nl) {
+__global__ __launch_bounds__(256) void k_isplit_pass(DevCtx c, const u64 *__restrict__ tsp_half, u64 *__restrict__ tpart, int nl,
+                                                     u32 fpmask) {
   static_assert(LB == 14, "split transforms are laid out for N = 2^14");
   const size_t cc = blockIdx.x >> 2;
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
@@ -155,11 +173,23 @@ __global__ __launch_bounds__(256) void k_isplit_pass(DevCtx c, const u64 *__rest
     const typename A::K kk = A::consts(m);
     const u64 hm = reduce64(ms.q >> 1, m);
     const u64 fix = hm ? m.q - hm : 0;
+    u64 *__restrict__ dst = tpart + (cc * nl + j) * PS;
+    if ((fpmask >> j) & 1u) {
+      const Mod mf = mod_at(c, j);
+      const FpTable tf = fp_table(c, j);
+      const FpK kf = FpArith::consts(mf);
+      double yd[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) yd[k] = fp_from_u64(add_mod(reduce64(x[k], m), fix, m.q));
+      fwd_pass<FpArith, LB, 0, 4>(yd, hi0, tf, kf, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 16; k++) reinterpret_cast<double *>(dst)[(k << 10) + p] = yd[k];
+      continue;
+    }
     u64 y[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) y[k] = add_mod(reduce64(x[k], m), fix, m.q);
     fwd_pass<A, LB, 0, 4>(y, hi0, t, kk, 0, 0);
-    u64 *__restrict__ dst = tpart + (cc * nl + j) * PS;
 #pragma unroll
     for (int k = 0; k < 16; k++) dst[(k << 10) + p] = y[k];
   }
@@ -177,7 +207,8 @@ template <int MODE, bool GAL, int NL, bool GUARD>
 __global__ __launch_bounds__(512, 4) void k_isplit_main(DevCtx c, const u64 *__restrict__ part, const u64 *__restrict__ tpart,
                                                         const u64 *__restrict__ opa, const u64 *__restrict__ opb, size_t opa_stride,
                                                         size_t opb_stride, int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out,
-                                                        u32 gelt) {
+                                                        u32 gelt, u32 imap, int ni) {
+  // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all of them: 0x3210, ni = nl)
   extern __shared__ u64 dynu[];  // nl + 1 transform buffers, then the block's twiddle table (1024 {w, Shoup} pairs)
   static_assert(NL + 1 <= 8, "one wavefront per limb, eight wavefronts");
   constexpr int nl = NL, NT = 512, PER = 2;
@@ -185,8 +216,8 @@ __global__ __launch_bounds__(512, 4) void k_isplit_main(DevCtx c, const u64 *__r
   const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int blk = blockIdx.x & 15;
-  const int I = (int)((blockIdx.x >> 4) % nl);
-  const size_t ct = (size_t)((blockIdx.x >> 4) / nl);
+  const int I = (int)((imap >> (4 * ((blockIdx.x >> 4) % (unsigned)ni))) & 15u);
+  const size_t ct = (size_t)((blockIdx.x >> 4) / (unsigned)ni);
   const size_t N = (size_t)c.n, base = (size_t)blk << 10, PS = (size_t)c.ps;
   const Mod m = c.mods[I];
   const NttTable t = ntt_table(c, I);
@@ -303,22 +334,30 @@ __global__ __launch_bounds__(512, 4) void k_isplit_main(DevCtx c, const u64 *__r
 template <bool GUARD>
 static void launch_isplit_tail(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, u64 *part, u64 *tpart, u64 *tsp_half, int mode,
                                const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out,
-                               u32 gelt) {
+                               u32 gelt, u32 fpmask) {
   const size_t lds_sp = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
   const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
-  const dim3 gsp((unsigned)(cc * 16)), gmain((unsigned)(cc * nl * 16));
+  // data primes of the integer main kernel / of the fp64 main kernel, one nibble each
+  u32 imap_int = 0, imap_fp = 0;
+  int ni_int = 0, ni_fp = 0;
+  for (int I = 0; I < nl; I++) {
+    if ((fpmask >> I) & 1u) imap_fp |= (u32)I << (4 * ni_fp++);
+    else imap_int |= (u32)I << (4 * ni_int++);
+  }
+  const dim3 gsp((unsigned)(cc * 16)), gmain((unsigned)(cc * ni_int * 16));
 #define ABC_ISP(NLV)                                                                                                                  \
   hipLaunchKernelGGL((k_isplit_special<GUARD, NLV>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp_half);                    \
-  hipLaunchKernelGGL((k_isplit_pass<14, GUARD>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp_half, tpart, nl);         \
-  if (mode == 0)                                                                                                                      \
+  hipLaunchKernelGGL((k_isplit_pass<14, GUARD>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp_half, tpart, nl, fpmask); \
+  if (ni_int == 0) {                                                                                                                  \
+  } else if (mode == 0)                                                                                                               \
     hipLaunchKernelGGL((k_isplit_main<0, false, NLV, GUARD>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, \
-                       opb_stride, add_c1, key, out, gelt);                                                                           \
+                       opb_stride, add_c1, key, out, gelt, imap_int, ni_int);                                                         \
   else if (gelt)                                                                                                                      \
     hipLaunchKernelGGL((k_isplit_main<1, true, NLV, GUARD>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, \
-                       opb_stride, add_c1, key, out, gelt);                                                                           \
+                       opb_stride, add_c1, key, out, gelt, imap_int, ni_int);                                                         \
   else                                                                                                                                \
     hipLaunchKernelGGL((k_isplit_main<1, false, NLV, GUARD>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, \
-                       opb_stride, add_c1, key, out, gelt)
+                       opb_stride, add_c1, key, out, gelt, imap_int, ni_int)
   switch (nl) {
     case 1: ABC_ISP(1); break;
     case 2: ABC_ISP(2); break;
@@ -326,6 +365,9 @@ static void launch_isplit_tail(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     default: ABC_ISP(4); break;
   }
 #undef ABC_ISP
+  if (ni_fp)
+    split4_main_subset(st, c, cc, nl, mode, (const double *)part, (const double *)tpart, opa, opb, opa_stride, opb_stride, add_c1, key, out,
+                       gelt, imap_fp, ni_fp);
 }
 
 // scratch (words, limb stride c->dc.ps): part nl(nl+1) | tpart 2 nl | tsp_half 2
@@ -345,17 +387,22 @@ int isplit_chunk(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl
   u64 *part = scratch, *tpart = part + cc * (size_t)nl * (nl + 1) * PS, *tsp = tpart + cc * 2 * (size_t)nl * PS;
   bool guard = false;
   for (int j = 0; j < c->K; j++) guard = guard || !unguarded_ok(c->h_mods[j].bits);
+  // data primes below 2^50 take the fp64 kernels (ABC_HIP_NO_FP64 / ABC_HIP_NO_MIXED: integers throughout)
+  u32 fpmask = 0;
+  if (c->use_fp && !c->sw.no_mixed)
+    for (int j = 0; j < nl; j++)
+      if (fp_ok(c->h_mods[j].bits)) fpmask |= 1u << j;
   const dim3 g1((unsigned)(cc * nl)), b1((1 << 14) / 16);
   if (guard) {
-    if (mode == 0) hipLaunchKernelGGL((k_isplit_pass0<14, true, false, false>), g1, b1, 0, st, c->dc, opa, opb, 0, part, nl, 0u);
-    else if (gelt) hipLaunchKernelGGL((k_isplit_pass0<14, true, true, true>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, gelt);
-    else hipLaunchKernelGGL((k_isplit_pass0<14, true, true, false>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, 0u);
-    launch_isplit_tail<true>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt);
+    if (mode == 0) hipLaunchKernelGGL((k_isplit_pass0<14, true, false, false>), g1, b1, 0, st, c->dc, opa, opb, 0, part, nl, 0u, fpmask);
+    else if (gelt) hipLaunchKernelGGL((k_isplit_pass0<14, true, true, true>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, gelt, fpmask);
+    else hipLaunchKernelGGL((k_isplit_pass0<14, true, true, false>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, 0u, fpmask);
+    launch_isplit_tail<true>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
   } else {
-    if (mode == 0) hipLaunchKernelGGL((k_isplit_pass0<14, false, false, false>), g1, b1, 0, st, c->dc, opa, opb, 0, part, nl, 0u);
-    else if (gelt) hipLaunchKernelGGL((k_isplit_pass0<14, false, true, true>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, gelt);
-    else hipLaunchKernelGGL((k_isplit_pass0<14, false, true, false>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, 0u);
-    launch_isplit_tail<false>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt);
+    if (mode == 0) hipLaunchKernelGGL((k_isplit_pass0<14, false, false, false>), g1, b1, 0, st, c->dc, opa, opb, 0, part, nl, 0u, fpmask);
+    else if (gelt) hipLaunchKernelGGL((k_isplit_pass0<14, false, true, true>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, gelt, fpmask);
+    else hipLaunchKernelGGL((k_isplit_pass0<14, false, true, false>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, 0u, fpmask);
+    launch_isplit_tail<false>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
   }
   ABC_HIP_CHECK(hipGetLastError());
   return 0;

@@ -198,15 +198,21 @@ WIDE_CHAINS = {
     "60_40_40_60": [60, 40, 40, 60],      # guarded butterflies (k_fused_ks_decomp_ntt<LB,true,false>, moddown<LB,true>)
     "57_45_45_57": [57, 45, 45, 57],      # unguarded, non-lazy inner product (<LB,false,false>, moddown<LB,false>)
     "55_52_51_55": [55, 52, 51, 55],      # unguarded + lazy (<LB,false,true>) with every prime above the fp64 limit
-    "60_50_40_50": [60, 50, 40, 50],      # mixed: fp64-capable primes next to a 60-bit one (must not take the fp64 path)
+    "60_50_40_50": [60, 50, 40, 50],      # mixed: fp64-capable data primes next to a 60-bit one (those limbs take the fp64 kernels)
+    "60_40_40_40_60": [60, 40, 40, 40, 60],  # bench.py's value_60bit_primes chain: integer ends, fp64 middle
+    "50_40_58_40_50": [50, 40, 58, 40, 50],  # an integer prime between fp64 ones (the main kernels' prime maps are not contiguous)
 }
 
 
-@pytest.mark.parametrize("isplit", [True, False])
+@pytest.mark.parametrize("isplit", ["mixed", "integer_only", "round1"])
 @pytest.mark.parametrize("chain", list(WIDE_CHAINS))
 def test_ckks14_wide_prime_chains_every_level(chain, isplit, oracle_mod, capi, monkeypatch):
-    if not isplit:
-        monkeypatch.setenv("ABC_HIP_NO_ISPLIT", "1")  # the round-1 integer kernels stay selectable and tested
+    # mixed (default): data primes below 2^50 take the fp64 kernels inside the integer sequence; integer_only: the same sequence
+    # with integers throughout; round1: the round-1 integer kernels, which stay selectable and tested
+    if isplit == "integer_only":
+        monkeypatch.setenv("ABC_HIP_NO_MIXED", "1")
+    if isplit == "round1":
+        monkeypatch.setenv("ABC_HIP_NO_ISPLIT", "1")
     n = 16384
     primes = oracle_mod.create_primes(n, WIDE_CHAINS[chain])
     o = oracle_mod.Oracle(oracle_mod.CKKS, n, primes)
