@@ -17,6 +17,14 @@
 
 namespace abc {
 
+// x*y mod q for two residues |x|, |y| <= q in exact fp64 (as fp_mulmod of abc_kernels_fused.hip)
+__device__ __forceinline__ double i_fp_mulmod(double x, double y, double q, double qinv) {
+  const double h = x * y;
+  const double l = __builtin_fma(x, y, -h);
+  const double c = __builtin_rint(h * qinv);
+  return __builtin_fma(-c, q, h) + l;
+}
+
 template <int LB, class TW, int PER>
 __device__ __forceinline__ void block_twiddles_fetch_g(const TW *tw, int S0, int b, int tid, int nthreads, TW (&v)[PER]) {
 #pragma unroll
@@ -41,7 +49,21 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_isplit_pass0(DevCtx c, const
   const size_t N = (size_t)1 << LB, pw = (size_t)nl * N;
   const Mod m = c.mods[j];
   u64 src[16];
-  {
+  if ((fpmask >> j) & 1u) {  // q_j below 2^50: this limb's own inverse transform in exact fp64 (workgroup-uniform)
+    double *ldsd = reinterpret_cast<double *>(lds);
+    const Mod mf = mod_at(c, j);
+    const FpTable tf = fp_table(c, j);
+    const double q = mf.qd, qinv = mf.qinv;
+    auto canon = [&](int r, int, double v) { src[r] = fp_to_canon(fp_mul_lazy(v, mf.inv_n_c, mf.inv_n_cq, q), q, qinv); };
+    if (KS) {
+      const u64 *__restrict__ sp = a + ct * a_stride + (size_t)j * N;
+      ntt_inv_block_a<LB, FpArith>(ldsd, [&](int, int i) { return fp_from_u64(sp[galois_ntt_src<GAL>((u32)i, gelt, LB)]); }, canon, tf, mf, 0, 0);
+    } else {
+      const u64 *__restrict__ a1 = a + ct * 2 * pw + pw + (size_t)j * N, *__restrict__ b1 = b + ct * 2 * pw + pw + (size_t)j * N;
+      ntt_inv_block_a<LB, FpArith>(ldsd, [&](int, int i) { return i_fp_mulmod(fp_from_u64(a1[i]), fp_from_u64(b1[i]), q, qinv); }, canon, tf,
+                                   mf, 0, 0);
+    }
+  } else {
     const NttTable t = ntt_table(c, j);
     if (KS) {
       const u64 *__restrict__ sp = a + ct * a_stride + (size_t)j * N;
