@@ -1196,12 +1196,12 @@ struct PairOps {
 };
 
 template <int MODE, bool GAL, int NL>
-__global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const double *__restrict__ part,
+__global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx c, const double *__restrict__ part,
                                                                    const double *__restrict__ tpart, const u64 *__restrict__ opa,
                                                                    const u64 *__restrict__ opb, size_t opa_stride, size_t opb_stride,
                                                                    int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out, u32 gelt,
                                                                    u32 imap, int ni) {
-  // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all of them: 0x3210, ni = nl; a subset
+  // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all of them: 0x76543210, ni = nl; a subset
   // when a chain mixes fp64-capable and wider primes: abc_kernels_isplit.hip)
   extern __shared__ double dyn[];  // nl + 1 transform buffers, then the block's twiddle table (1024 {w, w/q} pairs)
   // 512 threads whatever nl: one coefficient pair per thread afterwards, so every operand of that phase is requested up front;
@@ -1337,8 +1337,8 @@ __global__ __launch_bounds__(512, 4) void k_split4_main_fp(DevCtx c, const doubl
 template <int MODE, bool GAL>
 static bool launch_split4_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const double *tpart, const u64 *opa,
                                const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt,
-                               u32 imap = 0x3210u, int ni = -1) {
-  if (nl < 1 || nl > 4) return false;
+                               u32 imap = 0x76543210u, int ni = -1) {
+  if (nl < 1 || nl > 7) return false;  // nl + 1 transform buffers of 8.5 KiB + the table: two workgroups per CU up to nl = 6, one at 7
   if (ni < 0) ni = nl;
   if (ni == 0) return true;
   const dim3 grid((unsigned)(cc * ni * 16)), block(512);
@@ -1350,7 +1350,10 @@ static bool launch_split4_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     case 1: ABC_TM4(1); break;
     case 2: ABC_TM4(2); break;
     case 3: ABC_TM4(3); break;
-    default: ABC_TM4(4); break;
+    case 4: ABC_TM4(4); break;
+    case 5: ABC_TM4(5); break;
+    case 6: ABC_TM4(6); break;
+    default: ABC_TM4(7); break;
   }
 #undef ABC_TM4
   return true;
@@ -1466,7 +1469,9 @@ static void launch_split3(hipStream_t st, abc_hip_ctx *c, const FusedScratch &s,
                                      (double *)s.tsp, gelt, 1);
   hipLaunchKernelGGL(k_split3_pass_fp<14>, dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, (const double *)s.tsp, (double *)s.ksacc,
                      nl);
-  if (!c->sw.no_split4 && launch_split4_main<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, (const double *)s.ksacc, opa, opb,
+  // (measured at nl = 5 / 6 / 7, every prime below 2^50: +9.5 / -5 / -14 % against k_split3_main_fp: above five limbs the prefetched
+  // key words push the kernel past 128 VGPRs and to one workgroup per CU)
+  if (!c->sw.no_split4 && nl <= 5 && launch_split4_main<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, (const double *)s.ksacc, opa, opb,
                                                         opa_stride, opb_stride, add_c1, key, out, gelt))
     return;
   launch_split3_main<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, (const double *)s.ksacc, opa, opb, opa_stride, opb_stride, add_c1,

@@ -226,11 +226,11 @@ struct IPairOps {
 };
 
 template <int MODE, bool GAL, int NL, bool GUARD>
-__global__ __launch_bounds__(512, 4) void k_isplit_main(DevCtx c, const u64 *__restrict__ part, const u64 *__restrict__ tpart,
+__global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_isplit_main(DevCtx c, const u64 *__restrict__ part, const u64 *__restrict__ tpart,
                                                         const u64 *__restrict__ opa, const u64 *__restrict__ opb, size_t opa_stride,
                                                         size_t opb_stride, int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out,
                                                         u32 gelt, u32 imap, int ni) {
-  // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all of them: 0x3210, ni = nl)
+  // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all of them: 0x76543210, ni = nl)
   extern __shared__ u64 dynu[];  // nl + 1 transform buffers, then the block's twiddle table (1024 {w, Shoup} pairs)
   static_assert(NL + 1 <= 8, "one wavefront per limb, eight wavefronts");
   constexpr int nl = NL, NT = 512, PER = 2;
@@ -384,7 +384,10 @@ static void launch_isplit_tail(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     case 1: ABC_ISP(1); break;
     case 2: ABC_ISP(2); break;
     case 3: ABC_ISP(3); break;
-    default: ABC_ISP(4); break;
+    case 4: ABC_ISP(4); break;
+    case 5: ABC_ISP(5); break;
+    case 6: ABC_ISP(6); break;
+    default: ABC_ISP(7); break;
   }
 #undef ABC_ISP
   if (ni_fp)
@@ -396,7 +399,7 @@ static void launch_isplit_tail(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
 size_t isplit_scratch_words(const abc_hip_ctx *c, int nl) { return ((size_t)nl * (nl + 1) + 2 * (size_t)nl + 2) * (size_t)c->dc.ps; }
 
 bool isplit_applies(const abc_hip_ctx *c, int nl) {
-  if (c->logn != 14 || c->scheme != 2 || c->sw.no_fused || c->sw.no_split || c->sw.no_isplit || nl < 1 || nl > 4) return false;
+  if (c->logn != 14 || c->scheme != 2 || c->sw.no_fused || c->sw.no_split || c->sw.no_isplit || nl < 1 || nl > 7) return false;
   for (int j = 0; j < c->K; j++)
     if (c->h_mods[j].bits > 60) return false;
   return true;

@@ -201,6 +201,9 @@ WIDE_CHAINS = {
     "60_50_40_50": [60, 50, 40, 50],      # mixed: fp64-capable data primes next to a 60-bit one (those limbs take the fp64 kernels)
     "60_40_40_40_60": [60, 40, 40, 40, 60],  # bench.py's value_60bit_primes chain: integer ends, fp64 middle
     "50_40_58_40_50": [50, 40, 58, 40, 50],  # an integer prime between fp64 ones (the main kernels' prime maps are not contiguous)
+    "60_40x4_60": [60, 40, 40, 40, 40, 60],  # five data limbs: the split kernels' 5..7-limb instantiations
+    "60_45x6_60": [60, 45, 45, 45, 45, 45, 45, 60],  # seven data limbs, mixed
+    "50_40x6_50": [50, 40, 40, 40, 40, 40, 40, 50],  # seven data limbs, every prime below 2^50 (fp64 sequence)
 }
 
 
