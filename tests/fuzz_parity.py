@@ -66,7 +66,7 @@ def draw_case(rng, max_logn):
             b = int(rng.choice([36, 40, 45, 49, 50, 52, 55, 58]))
             case["bits"] = [b] * L + [min(b + 1, 60)]
     else:
-        L = int(rng.integers(1, 5))
+        L = int(rng.integers(1, 8)) if rng.integers(0, 3) == 0 else int(rng.integers(1, 5))  # up to seven data limbs
         style = int(rng.integers(0, 4))
         if style == 0:
             bits = [50] + [40] * (L - 1) + [50]
