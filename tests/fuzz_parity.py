@@ -184,7 +184,7 @@ def main():
     from abc_amd import capi
     rng = np.random.default_rng(a.seed)
     contexts, counts = {}, {}
-    t0 = time.time()
+    t0 = last_note = time.time()
     done = 0
     while time.time() - t0 < a.seconds and (not a.max_cases or done < a.max_cases):
         case = draw_case(rng, a.max_logn)
@@ -192,6 +192,9 @@ def main():
         done += 1
         tag = "%s/%s" % (case["scheme"], case["op"])
         counts[tag] = counts.get(tag, 0) + (res == "ok")
+        if time.time() - last_note > 60:
+            last_note = time.time()
+            print("... %d cases, %.0f s" % (done, time.time() - t0), flush=True)
         if res.startswith("MISMATCH"):
             print(json.dumps({"result": res, "case": case}), flush=True)
             sys.exit(1)
