@@ -1742,6 +1742,11 @@ int ckks_mul_relin_fused(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
     const size_t ctw = 2 * (size_t)nl * c->n;
     return run_gsplit15(c, 0, a, b, ctw, ctw, false, c->d_relin, out, nl, count, 0u);
   }
+  if (c->logn == 15 && !all_fp(c) && isplit_applies(c, nl)) {  // a prime above 2^50: the integer split sequence with 32 blocks
+    if (!count) return 0;
+    const size_t ctw = 2 * (size_t)nl * c->n;
+    return run_isplit(c, 0, a, b, ctw, ctw, false, c->d_relin, out, nl, count, 0u);
+  }
   if (c->logn > 14) return -1;
   if (c->sw.no_fused) return -1;
   if (!count) return 0;
@@ -1852,6 +1857,11 @@ int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *ou
     const size_t pw15 = (size_t)nl * c->n;
     return run_gsplit15(c, 1, in + pw15, in, 2 * pw15, 2 * pw15, false, key, out, nl, count, elt);
   }
+  if (c->logn == 15 && c->scheme == 2 && in != out && !all_fp(c) && isplit_applies(c, nl) && !c->sw.no_galois_fusion) {
+    if (!count) return 0;
+    const size_t pw15 = (size_t)nl * c->n;
+    return run_isplit(c, 1, in + pw15, in, 2 * pw15, 2 * pw15, false, key, out, nl, count, elt);
+  }
   if (c->logn != 14 || c->scheme != 2 || in == out) return -1;
   if (!all_fp(c) && !isplit_applies(c, nl)) return -1;
   if (c->sw.no_split || c->sw.no_fused || c->sw.no_galois_fusion) return -1;
@@ -1865,6 +1875,10 @@ int keyswitch_fused(abc_hip_ctx *c, const u64 *target, size_t target_stride, con
   if (c->logn == 15 && gsplit_applies(c, nl)) {
     if (!count) return 0;
     return run_gsplit15(c, 1, target, addend, target_stride, addend_stride, add_c1, key, out, nl, count, 0u);
+  }
+  if (c->logn == 15 && c->scheme == 2 && !all_fp(c) && isplit_applies(c, nl)) {
+    if (!count) return 0;
+    return run_isplit(c, 1, target, addend, target_stride, addend_stride, add_c1, key, out, nl, count, 0u);
   }
   if (bsplit_big_applies(c, nl)) {  // BFV, N = 2^15 / 2^16, fp64-capable chain
     if (!count) return 0;

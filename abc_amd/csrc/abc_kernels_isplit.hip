@@ -25,6 +25,33 @@ __device__ __forceinline__ double i_fp_mulmod(double x, double y, double q, doub
   return __builtin_fma(-c, q, h) + l;
 }
 
+// radix-2^R pass over the 2^R values one thread holds, one from each 1024-point block (array index = block index): the first R
+// stages of a forward transform / the last R of an inverse one, in the arithmetic A of the prime (integer or fp64)
+template <int R, class A>
+__device__ __forceinline__ void x_fwd_cross(typename A::E (&x)[1 << R], const typename A::Table &t, const typename A::K &kk) {
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      A::fwd(x[k], x[k | half], tw_load(t.tw + (1 << u) + (k >> (R - u))), kk);
+    }
+  }
+}
+template <int R, class A>
+__device__ __forceinline__ void x_inv_cross(typename A::E (&x)[1 << R], const typename A::Table &t, const typename A::K &kk) {
+#pragma unroll
+  for (int u = R - 1; u >= 0; u--) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      A::inv(x[k], x[k | half], tw_load(t.itw + (1 << u) + (k >> (R - u))), kk);
+    }
+  }
+}
+
 template <int LB, class TW, int PER>
 __device__ __forceinline__ void block_twiddles_fetch_g(const TW *tw, int S0, int b, int tid, int nthreads, TW (&v)[PER]) {
 #pragma unroll
@@ -115,17 +142,96 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_isplit_pass0(DevCtx c, const
   }
 }
 
+// ---- N = 2^15: a limb is 256 KiB, nothing is LDS-resident -- the first step in two kernels (cf. abc_kernels_gsplit.hip) ----
+// K1a (limb j, block; four ciphertexts per workgroup, one wavefront each): operand block (a1 b1 for a multiply; the operand with
+//     the Galois gather folded in for a key switch) -> stages LOGN-1..LB of the inverse transform -> hinv (values in [0, 2q))
+template <int LOGN, int MODE, bool GAL>
+__global__ __launch_bounds__(256) void k_igsplit_inv_tails(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b, size_t a_stride,
+                                                           u64 *__restrict__ hinv, int nl, int cc, u32 gelt) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  extern __shared__ u64 dynu[];  // 4 transform buffers, then the block's inverse-twiddle table
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & (NB - 1);
+  const int j = (int)((blockIdx.x >> LOGNB) % (unsigned)nl);
+  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)nl) * 4 + (size_t)W;
+  const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps, pw = (size_t)nl * N;
+  const Mod m = c.mods[j];
+  const NttTable t = ntt_table(c, j);
+  u64x2 *litw = reinterpret_cast<u64x2 *>(dynu + 4 * lds_words(10));
+  u64x2 twv[4];
+  block_twiddles_fetch_g<10, u64x2, 4>(t.itw, LOGNB, blk, (int)threadIdx.x, 256, twv);
+  block_twiddles_store<10, u64x2, 4>(litw, (int)threadIdx.x, 256, twv);
+  __syncthreads();
+  if (ct >= (size_t)cc) return;  // wavefront-uniform, after the only workgroup barrier
+  u64 *buf = dynu + W * lds_words(10);
+  u64 *__restrict__ dst = hinv + (ct * nl + j) * PS + base;
+  auto st = [&](int, int i, u64 v) { dst[i] = v; };
+  if (MODE == 0) {
+    const u64 *__restrict__ a1 = a + ct * 2 * pw + pw + (size_t)j * N + base, *__restrict__ b1 = b + ct * 2 * pw + pw + (size_t)j * N + base;
+    auto ld = [&](int, int i) { return mul_mod(a1[i], b1[i], m); };
+    ntt_inv_block_a<10, IntArith<true>, decltype(ld), decltype(st), true>(buf, ld, st, t, m, LOGNB, blk, lane, litw);
+  } else {
+    const u64 *__restrict__ sp = a + ct * a_stride + (size_t)j * N;
+    auto ld = [&](int, int i) { return sp[galois_ntt_src<GAL>((u32)(base + i), gelt, LOGN)]; };
+    ntt_inv_block_a<10, IntArith<true>, decltype(ld), decltype(st), true>(buf, ld, st, t, m, LOGNB, blk, lane, litw);
+  }
+}
+// K1b (registers only): the cross pass of that inverse transform, N^-1, canonical coefficient; per other key prime the forward
+//     cross pass -> half-done decomposition limbs `part`
+template <int LOGN, bool GUARD>
+__global__ __launch_bounds__(256) void k_igsplit_cross(DevCtx c, const u64 *__restrict__ hinv, u64 *__restrict__ part, int nl) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
+  const int j = (int)((blockIdx.x >> 2) % (unsigned)nl);
+  const size_t ct = (size_t)((blockIdx.x >> 2) / (unsigned)nl);
+  const size_t PS = (size_t)c.ps;
+  const Mod m = c.mods[j];
+  u64 x[NB];
+  {
+    const NttTable t = ntt_table(c, j);
+    const IntArith<true>::K ks = IntArith<true>::consts(m);
+    const u64 *__restrict__ src = hinv + (ct * nl + j) * PS;
+#pragma unroll
+    for (int k = 0; k < NB; k++) x[k] = src[(k << 10) + p];
+    x_inv_cross<LOGNB, IntArith<true>>(x, t, ks);
+#pragma unroll
+    for (int k = 0; k < NB; k++) x[k] = scale_inv_n(x[k], m);  // canonical [0, q_j)
+  }
+  using A = IntArith<GUARD>;
+  for (int I = 0; I <= nl; I++) {
+    if (I == j) continue;
+    const int ki = (I == nl) ? c.K - 1 : I;
+    const Mod mI = c.mods[ki];
+    const NttTable t = ntt_table(c, ki);
+    const typename A::K kk = A::consts(mI);
+    const bool need_reduce = GUARD ? (m.q > mI.q) : ((m.q >> 3) >= mI.q);  // as k_isplit_pass0
+    u64 y[NB];
+    if (need_reduce) {
+#pragma unroll
+      for (int k = 0; k < NB; k++) y[k] = reduce64(x[k], mI);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; k++) y[k] = x[k];
+    }
+    x_fwd_cross<LOGNB, A>(y, t, kk);
+    u64 *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * PS;
+#pragma unroll
+    for (int k = 0; k < NB; k++) dst[(k << 10) + p] = y[k];
+  }
+}
+
 // K2a: the special prime's inner product and the block-local stages of its inverse transform (cf. k_split2_tailmac_fp)
-template <bool GUARD, int NL>
+template <bool GUARD, int NL, int LOGN>
 __global__ __launch_bounds__(NL * 64) void k_isplit_special(DevCtx c, const u64 *__restrict__ part, const u64 *__restrict__ key,
                                                             u64 *__restrict__ tsp_half) {
   extern __shared__ u64 dynu[];  // max(nl, 2) buffers of one 1024-point block
-  constexpr int nl = NL;
+  constexpr int nl = NL, LOGNB = LOGN - 10, NB = 1 << LOGNB;
   using A = IntArith<GUARD>;
   const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const int blk = blockIdx.x & 15;
-  const size_t ct = (size_t)(blockIdx.x >> 4);
+  const int blk = blockIdx.x & (NB - 1);
+  const size_t ct = (size_t)(blockIdx.x >> LOGNB);
   const size_t N = (size_t)c.n, base = (size_t)blk << 10, PS = (size_t)c.ps;
   const int ki = c.K - 1;
   const Mod m = c.mods[ki];
@@ -134,7 +240,7 @@ __global__ __launch_bounds__(NL * 64) void k_isplit_special(DevCtx c, const u64 
     u64 *buf = dynu + J * lds_words(10);
     const u64 *__restrict__ src = part + ((ct * (nl + 1) + nl) * nl + J) * PS + base;
     ntt_fwd_block_a<10, A>(
-        buf, [&](int, int i) { return src[i]; }, [&](int, int i, u64 v) { buf[lds_pad(i)] = canon_fwd<GUARD>(v, m); }, t, m, 4, blk,
+        buf, [&](int, int i) { return src[i]; }, [&](int, int i, u64 v) { buf[lds_pad(i)] = canon_fwd<GUARD>(v, m); }, t, m, LOGNB, blk,
         lane);
   }
   __syncthreads();
@@ -161,7 +267,7 @@ __global__ __launch_bounds__(NL * 64) void k_isplit_special(DevCtx c, const u64 
     u64 *buf = dynu + comp * lds_words(10);
     u64 *__restrict__ dst = tsp_half + (ct * 2 + comp) * PS + base;
     ntt_inv_block_a<10, IntArith<true>>(
-        buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, u64 v) { dst[i] = v; }, t, m, 4, blk, lane);
+        buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, u64 v) { dst[i] = v; }, t, m, LOGNB, blk, lane);
   }
 }
 
@@ -170,29 +276,27 @@ __global__ __launch_bounds__(NL * 64) void k_isplit_special(DevCtx c, const u64 
 template <int LB, bool GUARD>
 __global__ __launch_bounds__(256) void k_isplit_pass(DevCtx c, const u64 *__restrict__ tsp_half, u64 *__restrict__ tpart, int nl,
                                                      u32 fpmask) {
-  static_assert(LB == 14, "split transforms are laid out for N = 2^14");
+  static_assert(LB == 14 || LB == 15, "split transforms: 16 or 32 blocks of 1024 points");
+  constexpr int LOGNB = LB - 10, NB = 1 << LOGNB;
   const size_t cc = blockIdx.x >> 2;
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
-  const int hi0[1] = {0};
   const size_t PS = (size_t)c.ps;
-  u64 x[16];
+  u64 x[NB];
   const Mod ms = c.mods[c.K - 1];
   {
     const NttTable ts = ntt_table(c, c.K - 1);
     const IntArith<true>::K ks = IntArith<true>::consts(ms);
     const u64 *__restrict__ src = tsp_half + cc * PS;
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = src[(k << 10) + p];
-    inv_pass<IntArith<true>, LB, 0, 4>(x, hi0, ts, ks, 0, 0);
+    for (int k = 0; k < NB; k++) x[k] = src[(k << 10) + p];
+    x_inv_cross<LOGNB, IntArith<true>>(x, ts, ks);
     const u64 half = ms.q >> 1;
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = add_mod(scale_inv_n(x[k], ms), half, ms.q);  // canonical [0, q_sp)
+    for (int k = 0; k < NB; k++) x[k] = add_mod(scale_inv_n(x[k], ms), half, ms.q);  // canonical [0, q_sp)
   }
   using A = IntArith<GUARD>;
   for (int j = 0; j < nl; j++) {
     const Mod m = c.mods[j];
-    const NttTable t = ntt_table(c, j);
-    const typename A::K kk = A::consts(m);
     const u64 hm = reduce64(ms.q >> 1, m);
     const u64 fix = hm ? m.q - hm : 0;
     u64 *__restrict__ dst = tpart + (cc * nl + j) * PS;
@@ -200,20 +304,22 @@ __global__ __launch_bounds__(256) void k_isplit_pass(DevCtx c, const u64 *__rest
       const Mod mf = mod_at(c, j);
       const FpTable tf = fp_table(c, j);
       const FpK kf = FpArith::consts(mf);
-      double yd[16];
+      double yd[NB];
 #pragma unroll
-      for (int k = 0; k < 16; k++) yd[k] = fp_from_u64(add_mod(reduce64(x[k], m), fix, m.q));
-      fwd_pass<FpArith, LB, 0, 4>(yd, hi0, tf, kf, 0, 0);
+      for (int k = 0; k < NB; k++) yd[k] = fp_from_u64(add_mod(reduce64(x[k], m), fix, m.q));
+      x_fwd_cross<LOGNB, FpArith>(yd, tf, kf);
 #pragma unroll
-      for (int k = 0; k < 16; k++) reinterpret_cast<double *>(dst)[(k << 10) + p] = yd[k];
+      for (int k = 0; k < NB; k++) reinterpret_cast<double *>(dst)[(k << 10) + p] = yd[k];
       continue;
     }
-    u64 y[16];
+    const NttTable t = ntt_table(c, j);
+    const typename A::K kk = A::consts(m);
+    u64 y[NB];
 #pragma unroll
-    for (int k = 0; k < 16; k++) y[k] = add_mod(reduce64(x[k], m), fix, m.q);
-    fwd_pass<A, LB, 0, 4>(y, hi0, t, kk, 0, 0);
+    for (int k = 0; k < NB; k++) y[k] = add_mod(reduce64(x[k], m), fix, m.q);
+    x_fwd_cross<LOGNB, A>(y, t, kk);
 #pragma unroll
-    for (int k = 0; k < 16; k++) dst[(k << 10) + p] = y[k];
+    for (int k = 0; k < NB; k++) dst[(k << 10) + p] = y[k];
   }
 }
 
@@ -225,7 +331,7 @@ struct IPairOps {
   u64 xs[2], d0s[2], d1s[2];  // MODE 1
 };
 
-template <int MODE, bool GAL, int NL, bool GUARD>
+template <int MODE, bool GAL, int NL, bool GUARD, int LOGN>
 __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_isplit_main(DevCtx c, const u64 *__restrict__ part, const u64 *__restrict__ tpart,
                                                         const u64 *__restrict__ opa, const u64 *__restrict__ opb, size_t opa_stride,
                                                         size_t opb_stride, int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out,
@@ -233,13 +339,13 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_isplit_main(DevCtx c, 
   // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all of them: 0x76543210, ni = nl)
   extern __shared__ u64 dynu[];  // nl + 1 transform buffers, then the block's twiddle table (1024 {w, Shoup} pairs)
   static_assert(NL + 1 <= 8, "one wavefront per limb, eight wavefronts");
-  constexpr int nl = NL, NT = 512, PER = 2;
+  constexpr int nl = NL, NT = 512, PER = 2, LOGNB = LOGN - 10, NB = 1 << LOGNB;
   using A = IntArith<GUARD>;
   const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const int blk = blockIdx.x & 15;
-  const int I = (int)((imap >> (4 * ((blockIdx.x >> 4) % (unsigned)ni))) & 15u);
-  const size_t ct = (size_t)((blockIdx.x >> 4) / (unsigned)ni);
+  const int blk = blockIdx.x & (NB - 1);
+  const int I = (int)((imap >> (4 * ((blockIdx.x >> LOGNB) % (unsigned)ni))) & 15u);
+  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)ni);
   const size_t N = (size_t)c.n, base = (size_t)blk << 10, PS = (size_t)c.ps;
   const Mod m = c.mods[I];
   const NttTable t = ntt_table(c, I);
@@ -250,7 +356,7 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_isplit_main(DevCtx c, 
   const u64 inv = cst->inv_special[I], inv_s = cst->inv_special_s[I];
 
   u64x2 twv[PER];
-  block_twiddles_fetch_g<10, u64x2, PER>(t.tw, 4, blk, (int)threadIdx.x, NT, twv);
+  block_twiddles_fetch_g<10, u64x2, PER>(t.tw, LOGNB, blk, (int)threadIdx.x, NT, twv);
   const bool has_limb = W <= nl;
   const int Wc = has_limb ? W : 0;
   const u64 *__restrict__ src = (Wc < nl - 1) ? part + ((ct * (nl + 1) + I) * nl + (Wc < I ? Wc : Wc + 1)) * PS + base
@@ -293,7 +399,7 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_isplit_main(DevCtx c, 
   __syncthreads();
   if (has_limb) {
     u64 *buf = dynu + W * lds_words(10);
-    ntt_fwd_tail1024_pairs<A>(buf, xin, [&](int, int i, u64 v) { buf[lds_pad(i)] = canon_fwd<GUARD>(v, m); }, t, m, 4, blk, lane, ltw);
+    ntt_fwd_tail1024_pairs<A>(buf, xin, [&](int, int i, u64 v) { buf[lds_pad(i)] = canon_fwd<GUARD>(v, m); }, t, m, LOGNB, blk, lane, ltw);
   }
   __syncthreads();
   const u64 *tt0 = dynu + (nl - 1) * lds_words(10), *tt1 = dynu + nl * lds_words(10);
@@ -353,7 +459,7 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_isplit_main(DevCtx c, 
 }
 
 // ---- launch sequence on one chunk ----
-template <bool GUARD>
+template <bool GUARD, int LOGN>
 static void launch_isplit_tail(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, u64 *part, u64 *tpart, u64 *tsp_half, int mode,
                                const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out,
                                u32 gelt, u32 fpmask) {
@@ -366,19 +472,20 @@ static void launch_isplit_tail(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     if ((fpmask >> I) & 1u) imap_fp |= (u32)I << (4 * ni_fp++);
     else imap_int |= (u32)I << (4 * ni_int++);
   }
-  const dim3 gsp((unsigned)(cc * 16)), gmain((unsigned)(cc * ni_int * 16));
+  constexpr int NB = 1 << (LOGN - 10);
+  const dim3 gsp((unsigned)(cc * NB)), gmain((unsigned)(cc * ni_int * NB));
 #define ABC_ISP(NLV)                                                                                                                  \
-  hipLaunchKernelGGL((k_isplit_special<GUARD, NLV>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp_half);                    \
-  hipLaunchKernelGGL((k_isplit_pass<14, GUARD>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp_half, tpart, nl, fpmask); \
+  hipLaunchKernelGGL((k_isplit_special<GUARD, NLV, LOGN>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp_half);              \
+  hipLaunchKernelGGL((k_isplit_pass<LOGN, GUARD>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp_half, tpart, nl, fpmask); \
   if (ni_int == 0) {                                                                                                                  \
   } else if (mode == 0)                                                                                                               \
-    hipLaunchKernelGGL((k_isplit_main<0, false, NLV, GUARD>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, \
+    hipLaunchKernelGGL((k_isplit_main<0, false, NLV, GUARD, LOGN>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, \
                        opb_stride, add_c1, key, out, gelt, imap_int, ni_int);                                                         \
   else if (gelt)                                                                                                                      \
-    hipLaunchKernelGGL((k_isplit_main<1, true, NLV, GUARD>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, \
+    hipLaunchKernelGGL((k_isplit_main<1, true, NLV, GUARD, LOGN>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, \
                        opb_stride, add_c1, key, out, gelt, imap_int, ni_int);                                                         \
   else                                                                                                                                \
-    hipLaunchKernelGGL((k_isplit_main<1, false, NLV, GUARD>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, \
+    hipLaunchKernelGGL((k_isplit_main<1, false, NLV, GUARD, LOGN>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, \
                        opb_stride, add_c1, key, out, gelt, imap_int, ni_int)
   switch (nl) {
     case 1: ABC_ISP(1); break;
@@ -396,10 +503,15 @@ static void launch_isplit_tail(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
 }
 
 // scratch (words, limb stride c->dc.ps): part nl(nl+1) | tpart 2 nl | tsp_half 2
-size_t isplit_scratch_words(const abc_hip_ctx *c, int nl) { return ((size_t)nl * (nl + 1) + 2 * (size_t)nl + 2) * (size_t)c->dc.ps; }
+// (N = 2^15: + hinv nl, the operand after the block stages of its inverse transform)
+size_t isplit_scratch_words(const abc_hip_ctx *c, int nl) {
+  return ((size_t)nl * (nl + 1) + 2 * (size_t)nl + 2 + (c->logn == 15 ? (size_t)nl : 0)) * (size_t)c->dc.ps;
+}
 
 bool isplit_applies(const abc_hip_ctx *c, int nl) {
-  if (c->logn != 14 || c->scheme != 2 || c->sw.no_fused || c->sw.no_split || c->sw.no_isplit || nl < 1 || nl > 7) return false;
+  if ((c->logn != 14 && c->logn != 15) || c->scheme != 2 || c->sw.no_fused || c->sw.no_split || c->sw.no_isplit || nl < 1 || nl > 7)
+    return false;
+  if (c->logn == 15 && (nl > 4 || c->sw.no_gsplit)) return false;  // 32 blocks: instantiated for the chains of configs 3-4 depth
   for (int j = 0; j < c->K; j++)
     if (c->h_mods[j].bits > 60) return false;
   return true;
@@ -412,6 +524,26 @@ int isplit_chunk(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl
   u64 *part = scratch, *tpart = part + cc * (size_t)nl * (nl + 1) * PS, *tsp = tpart + cc * 2 * (size_t)nl * PS;
   bool guard = false;
   for (int j = 0; j < c->K; j++) guard = guard || !unguarded_ok(c->h_mods[j].bits);
+  if (c->logn == 15) {  // integers throughout (the fp64 main kernel of this ring has no prime map yet)
+    u64 *hinv = tsp + cc * 2 * PS;
+    const dim3 ga((unsigned)(((cc + 3) / 4) * nl * 32)), gb((unsigned)(cc * nl * 4));
+    const size_t lds = (size_t)(4 * lds_words(10)) * 8 + 1024 * 16;
+    if (mode == 0)
+      hipLaunchKernelGGL((k_igsplit_inv_tails<15, 0, false>), ga, dim3(256), lds, st, c->dc, opa, opb, 0, hinv, nl, (int)cc, 0u);
+    else if (gelt)
+      hipLaunchKernelGGL((k_igsplit_inv_tails<15, 1, true>), ga, dim3(256), lds, st, c->dc, opa, nullptr, opa_stride, hinv, nl, (int)cc, gelt);
+    else
+      hipLaunchKernelGGL((k_igsplit_inv_tails<15, 1, false>), ga, dim3(256), lds, st, c->dc, opa, nullptr, opa_stride, hinv, nl, (int)cc, 0u);
+    if (guard) {
+      hipLaunchKernelGGL((k_igsplit_cross<15, true>), gb, dim3(256), 0, st, c->dc, hinv, part, nl);
+      launch_isplit_tail<true, 15>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, 0u);
+    } else {
+      hipLaunchKernelGGL((k_igsplit_cross<15, false>), gb, dim3(256), 0, st, c->dc, hinv, part, nl);
+      launch_isplit_tail<false, 15>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, 0u);
+    }
+    ABC_HIP_CHECK(hipGetLastError());
+    return 0;
+  }
   // data primes below 2^50 take the fp64 kernels (ABC_HIP_NO_FP64 / ABC_HIP_NO_MIXED: integers throughout)
   u32 fpmask = 0;
   if (c->use_fp && !c->sw.no_mixed)
@@ -422,12 +554,12 @@ int isplit_chunk(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl
     if (mode == 0) hipLaunchKernelGGL((k_isplit_pass0<14, true, false, false>), g1, b1, 0, st, c->dc, opa, opb, 0, part, nl, 0u, fpmask);
     else if (gelt) hipLaunchKernelGGL((k_isplit_pass0<14, true, true, true>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, gelt, fpmask);
     else hipLaunchKernelGGL((k_isplit_pass0<14, true, true, false>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, 0u, fpmask);
-    launch_isplit_tail<true>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
+    launch_isplit_tail<true, 14>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
   } else {
     if (mode == 0) hipLaunchKernelGGL((k_isplit_pass0<14, false, false, false>), g1, b1, 0, st, c->dc, opa, opb, 0, part, nl, 0u, fpmask);
     else if (gelt) hipLaunchKernelGGL((k_isplit_pass0<14, false, true, true>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, gelt, fpmask);
     else hipLaunchKernelGGL((k_isplit_pass0<14, false, true, false>), g1, b1, 0, st, c->dc, opa, nullptr, opa_stride, part, nl, 0u, fpmask);
-    launch_isplit_tail<false>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
+    launch_isplit_tail<false, 14>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
   }
   ABC_HIP_CHECK(hipGetLastError());
   return 0;

@@ -143,18 +143,20 @@ def test_bfv_default_8192_and_16384(oracle_mod, capi):
         _eq("BFVDefault(%d) rotate" % n, g.rotate(a, 3), o.rotate(a, 3))
 
 
+@pytest.mark.parametrize("bits", [[50, 40, 40, 40, 50], [60, 40, 40, 40, 60], [57, 45, 45, 57]])
 @pytest.mark.parametrize("generic", [False, True])
-def test_ckks15_every_level_split_and_generic(generic, oracle_mod, capi, monkeypatch):
+def test_ckks15_every_level_split_and_generic(generic, bits, oracle_mod, capi, monkeypatch):
     """N = 2^15: the split key switch without LDS-resident limbs (abc_kernels_gsplit.hip) and the generic kernels it
     replaces (ABC_HIP_NO_GSPLIT=1) against the oracle: multiply + relinearise, rotation (direct and NAF), relinearize and
     key switch stand-alone, at every level, single and batched (ragged group of four in the block-tail kernel)."""
     if generic:
         monkeypatch.setenv("ABC_HIP_NO_GSPLIT", "1")
     n = 32768
-    primes = oracle_mod.create_primes(n, [50, 40, 40, 40, 50])
+    # every prime below 2^50: the fp64 sequence; a 60-bit (guarded) or 57-bit (unguarded) prime: its integer twin with 32 blocks
+    primes = oracle_mod.create_primes(n, bits)
     o, g = _pair(oracle_mod, capi, oracle_mod.CKKS, n, primes, seed=0xABC00F15)
     rng = np.random.default_rng(15)
-    L = 4
+    L = len(bits) - 1
     x = np.stack([rng.integers(0, q, size=(2, n), dtype=np.uint64) for q in primes[:L]], axis=1)
     y = np.stack([rng.integers(0, q, size=(2, n), dtype=np.uint64) for q in primes[:L]], axis=1)
     for j in range(L):  # adversarial residues: long runs at the ends of [0, q)
