@@ -288,15 +288,17 @@ template <int LOGN, int MODE, bool GAL, int NL>
 __global__ __launch_bounds__(512, 4) void k_gsplit_main(DevCtx c, const double *__restrict__ part, const double *__restrict__ tpart,
                                                         const u64 *__restrict__ opa, const u64 *__restrict__ opb, size_t opa_stride,
                                                         size_t opb_stride, int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out,
-                                                        u32 gelt) {
+                                                        u32 gelt, u32 imap, int ni) {
+  // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all: 0x76543210, ni = nl; a subset for
+  // chains that mix fp64-capable and wider primes: abc_kernels_isplit.hip)
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, nl = NL, NT = 512, PER = 2;
   extern __shared__ double dyn[];
   static_assert(NL + 1 <= 8, "one wavefront per limb, eight wavefronts");
   const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int blk = blockIdx.x & (NB - 1);
-  const int I = (int)((blockIdx.x >> LOGNB) % nl);
-  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / nl);
+  const int I = (int)((imap >> (4 * ((blockIdx.x >> LOGNB) % (unsigned)ni))) & 15u);
+  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)ni);
   const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps;
   const Mod m = mod_at(c, I);
   const FpTable t = fp_table(c, I);
@@ -433,13 +435,13 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp, tpart, nl);                     \
   if (mode == 0)                                                                                                                        \
     hipLaunchKernelGGL((k_gsplit_main<LOGN, 0, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,  \
-                       opb_stride, add_c1, key, out, gelt);                                                                             \
+                       opb_stride, add_c1, key, out, gelt, 0x76543210u, nl);                                                                             \
   else if (gelt)                                                                                                                        \
     hipLaunchKernelGGL((k_gsplit_main<LOGN, 1, true, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,   \
-                       opb_stride, add_c1, key, out, gelt);                                                                             \
+                       opb_stride, add_c1, key, out, gelt, 0x76543210u, nl);                                                                             \
   else                                                                                                                                  \
     hipLaunchKernelGGL((k_gsplit_main<LOGN, 1, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,  \
-                       opb_stride, add_c1, key, out, gelt)
+                       opb_stride, add_c1, key, out, gelt, 0x76543210u, nl)
   switch (nl) {
     case 1: ABC_GSP(1); break;
     case 2: ABC_GSP(2); break;
@@ -447,6 +449,33 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     default: ABC_GSP(4); break;
   }
 #undef ABC_GSP
+}
+
+// the main step of N = 2^15 over a subset of the data primes (mixed chains, abc_kernels_isplit.hip): mode 0 multiply, mode 1 key switch
+bool gsplit_main_subset15(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const double *part, const double *tpart, const u64 *opa,
+                          const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt, u32 imap,
+                          int ni) {
+  if (nl < 1 || nl > 4 || ni < 1) return ni == 0;
+  const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
+  const dim3 gmain((unsigned)(cc * ni * 32));
+#define ABC_GSUB(NLV)                                                                                                                  \
+  if (mode == 0)                                                                                                                       \
+    hipLaunchKernelGGL((k_gsplit_main<15, 0, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,   \
+                       opb_stride, add_c1, key, out, gelt, imap, ni);                                                                  \
+  else if (gelt)                                                                                                                       \
+    hipLaunchKernelGGL((k_gsplit_main<15, 1, true, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,    \
+                       opb_stride, add_c1, key, out, gelt, imap, ni);                                                                  \
+  else                                                                                                                                 \
+    hipLaunchKernelGGL((k_gsplit_main<15, 1, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,   \
+                       opb_stride, add_c1, key, out, gelt, imap, ni)
+  switch (nl) {
+    case 1: ABC_GSUB(1); break;
+    case 2: ABC_GSUB(2); break;
+    case 3: ABC_GSUB(3); break;
+    default: ABC_GSUB(4); break;
+  }
+#undef ABC_GSUB
+  return true;
 }
 
 // scratch (words, limb stride c->dc.ps): hinv nl | part nl(nl+1) | tpart 2 nl | tsp_half 2

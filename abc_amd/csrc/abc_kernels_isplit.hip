@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_igsplit_inv_tails(DevCtx c, const u64 *
 // K1b (registers only): the cross pass of that inverse transform, N^-1, canonical coefficient; per other key prime the forward
 //     cross pass -> half-done decomposition limbs `part`
 template <int LOGN, bool GUARD>
-__global__ __launch_bounds__(256) void k_igsplit_cross(DevCtx c, const u64 *__restrict__ hinv, u64 *__restrict__ part, int nl) {
+__global__ __launch_bounds__(256) void k_igsplit_cross(DevCtx c, const u64 *__restrict__ hinv, u64 *__restrict__ part, int nl, u32 fpmask) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
   const int j = (int)((blockIdx.x >> 2) % (unsigned)nl);
@@ -203,6 +203,19 @@ __global__ __launch_bounds__(256) void k_igsplit_cross(DevCtx c, const u64 *__re
     if (I == j) continue;
     const int ki = (I == nl) ? c.K - 1 : I;
     const Mod mI = c.mods[ki];
+    u64 *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * PS;
+    if (I < nl && ((fpmask >> I) & 1u)) {  // q_I below 2^50: fp64 cross pass, raw doubles out (as k_isplit_pass0)
+      const Mod mf = mod_at(c, ki);
+      const FpTable tf = fp_table(c, ki);
+      const FpK kf = FpArith::consts(mf);
+      double yd[NB];
+#pragma unroll
+      for (int k = 0; k < NB; k++) yd[k] = fp_from_u64(reduce64(x[k], mI));
+      x_fwd_cross<LOGNB, FpArith>(yd, tf, kf);
+#pragma unroll
+      for (int k = 0; k < NB; k++) reinterpret_cast<double *>(dst)[(k << 10) + p] = yd[k];
+      continue;
+    }
     const NttTable t = ntt_table(c, ki);
     const typename A::K kk = A::consts(mI);
     const bool need_reduce = GUARD ? (m.q > mI.q) : ((m.q >> 3) >= mI.q);  // as k_isplit_pass0
@@ -215,7 +228,6 @@ __global__ __launch_bounds__(256) void k_igsplit_cross(DevCtx c, const u64 *__re
       for (int k = 0; k < NB; k++) y[k] = x[k];
     }
     x_fwd_cross<LOGNB, A>(y, t, kk);
-    u64 *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * PS;
 #pragma unroll
     for (int k = 0; k < NB; k++) dst[(k << 10) + p] = y[k];
   }
@@ -497,9 +509,12 @@ static void launch_isplit_tail(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     default: ABC_ISP(7); break;
   }
 #undef ABC_ISP
-  if (ni_fp)
+  if (ni_fp && LOGN == 14)
     split4_main_subset(st, c, cc, nl, mode, (const double *)part, (const double *)tpart, opa, opb, opa_stride, opb_stride, add_c1, key, out,
                        gelt, imap_fp, ni_fp);
+  else if (ni_fp)
+    gsplit_main_subset15(st, c, cc, nl, mode, (const double *)part, (const double *)tpart, opa, opb, opa_stride, opb_stride, add_c1, key, out,
+                         gelt, imap_fp, ni_fp);
 }
 
 // scratch (words, limb stride c->dc.ps): part nl(nl+1) | tpart 2 nl | tsp_half 2
@@ -524,7 +539,12 @@ int isplit_chunk(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl
   u64 *part = scratch, *tpart = part + cc * (size_t)nl * (nl + 1) * PS, *tsp = tpart + cc * 2 * (size_t)nl * PS;
   bool guard = false;
   for (int j = 0; j < c->K; j++) guard = guard || !unguarded_ok(c->h_mods[j].bits);
-  if (c->logn == 15) {  // integers throughout (the fp64 main kernel of this ring has no prime map yet)
+  // data primes below 2^50 take the fp64 kernels (ABC_HIP_NO_FP64 / ABC_HIP_NO_MIXED: integers throughout)
+  u32 fpmask = 0;
+  if (c->use_fp && !c->sw.no_mixed)
+    for (int j = 0; j < nl; j++)
+      if (fp_ok(c->h_mods[j].bits)) fpmask |= 1u << j;
+  if (c->logn == 15) {
     u64 *hinv = tsp + cc * 2 * PS;
     const dim3 ga((unsigned)(((cc + 3) / 4) * nl * 32)), gb((unsigned)(cc * nl * 4));
     const size_t lds = (size_t)(4 * lds_words(10)) * 8 + 1024 * 16;
@@ -535,20 +555,15 @@ int isplit_chunk(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl
     else
       hipLaunchKernelGGL((k_igsplit_inv_tails<15, 1, false>), ga, dim3(256), lds, st, c->dc, opa, nullptr, opa_stride, hinv, nl, (int)cc, 0u);
     if (guard) {
-      hipLaunchKernelGGL((k_igsplit_cross<15, true>), gb, dim3(256), 0, st, c->dc, hinv, part, nl);
-      launch_isplit_tail<true, 15>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, 0u);
+      hipLaunchKernelGGL((k_igsplit_cross<15, true>), gb, dim3(256), 0, st, c->dc, hinv, part, nl, fpmask);
+      launch_isplit_tail<true, 15>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
     } else {
-      hipLaunchKernelGGL((k_igsplit_cross<15, false>), gb, dim3(256), 0, st, c->dc, hinv, part, nl);
-      launch_isplit_tail<false, 15>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, 0u);
+      hipLaunchKernelGGL((k_igsplit_cross<15, false>), gb, dim3(256), 0, st, c->dc, hinv, part, nl, fpmask);
+      launch_isplit_tail<false, 15>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
     }
     ABC_HIP_CHECK(hipGetLastError());
     return 0;
   }
-  // data primes below 2^50 take the fp64 kernels (ABC_HIP_NO_FP64 / ABC_HIP_NO_MIXED: integers throughout)
-  u32 fpmask = 0;
-  if (c->use_fp && !c->sw.no_mixed)
-    for (int j = 0; j < nl; j++)
-      if (fp_ok(c->h_mods[j].bits)) fpmask |= 1u << j;
   const dim3 g1((unsigned)(cc * nl)), b1((1 << 14) / 16);
   if (guard) {
     if (mode == 0) hipLaunchKernelGGL((k_isplit_pass0<14, true, false, false>), g1, b1, 0, st, c->dc, opa, opb, 0, part, nl, 0u, fpmask);

@@ -143,13 +143,15 @@ def test_bfv_default_8192_and_16384(oracle_mod, capi):
         _eq("BFVDefault(%d) rotate" % n, g.rotate(a, 3), o.rotate(a, 3))
 
 
-@pytest.mark.parametrize("bits", [[50, 40, 40, 40, 50], [60, 40, 40, 40, 60], [57, 45, 45, 57]])
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("bits", [[50, 40, 40, 40, 50], [60, 40, 40, 40, 60], [57, 45, 45, 57], [50, 58, 40, 55]])
+@pytest.mark.parametrize("generic", [False, True, "integer_only"])
 def test_ckks15_every_level_split_and_generic(generic, bits, oracle_mod, capi, monkeypatch):
     """N = 2^15: the split key switch without LDS-resident limbs (abc_kernels_gsplit.hip) and the generic kernels it
     replaces (ABC_HIP_NO_GSPLIT=1) against the oracle: multiply + relinearise, rotation (direct and NAF), relinearize and
     key switch stand-alone, at every level, single and batched (ragged group of four in the block-tail kernel)."""
-    if generic:
+    if generic == "integer_only":  # wide chains: no fp64 kernels for the limbs of primes below 2^50
+        monkeypatch.setenv("ABC_HIP_NO_MIXED", "1")
+    elif generic:
         monkeypatch.setenv("ABC_HIP_NO_GSPLIT", "1")
     n = 32768
     # every prime below 2^50: the fp64 sequence; a 60-bit (guarded) or 57-bit (unguarded) prime: its integer twin with 32 blocks
