@@ -25,6 +25,8 @@ SWITCH_SETS = [
     {"ABC_HIP_CHUNK": "3", "ABC_HIP_LANES": "2"},
     {"ABC_HIP_CHUNK": "2", "ABC_HIP_LANES": "1"},
     {"ABC_HIP_NO_FP64": "1"},
+    {"ABC_HIP_NO_MIXED": "1"},
+    {"ABC_HIP_NO_ISPLIT": "1"},
     {"ABC_HIP_NO_SPLIT": "1"},
     {"ABC_HIP_NO_SPLIT3": "1"},
     {"ABC_HIP_NO_LEAN_FRONT": "1"},
