@@ -362,12 +362,95 @@ static int launch_rescale_fp(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, si
   return 0;
 }
 
+// The same two kernels with the arithmetic chosen per prime (chains that contain a prime above 2^50): the inverse transform runs in
+// the arithmetic of the dropped prime, each forward transform in that of its own prime j (bit j of fpmask: below 2^50).
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_rescale_intt_mixed(DevCtx c, const u64 *__restrict__ in, u64 *__restrict__ last, int nl,
+                                                                       int fp_last) {
+  __shared__ u64 lds_raw[lds_words(LB)];
+  const size_t N = (size_t)1 << LB;
+  const u64 *__restrict__ src = in + ((size_t)blockIdx.x * nl + (nl - 1)) * N;
+  u64 *__restrict__ dst = last + (size_t)blockIdx.x * N;
+  if (fp_last) {
+    const Mod m = mod_at(c, nl - 1);
+    const FpTable t = fp_table(c, nl - 1);
+    const double half = (double)(m.q >> 1);
+    ntt_inv_block_a<LB, FpArith>(
+        reinterpret_cast<double *>(lds_raw), [&](int, int i) { return fp_from_u64(src[i]); },
+        [&](int, int i, double v) { dst[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd) + half, m.qd, m.qinv); }, t, m, 0, 0);
+  } else {
+    const Mod m = c.mods[nl - 1];
+    const NttTable t = ntt_table(c, nl - 1);
+    const u64 half = m.q >> 1;
+    ntt_inv_block<LB>(
+        lds_raw, [&](int, int i) { return src[i]; }, [&](int, int i, u64 v) { dst[i] = add_mod(scale_inv_n(v, m), half, m.q); }, t, m, 0, 0);
+  }
+}
+template <int LB>
+__global__ __launch_bounds__((1 << LB) / 16) void k_rescale_ntt_mixed(DevCtx c, const u64 *__restrict__ in, const u64 *__restrict__ last,
+                                                                      u64 *__restrict__ out, int nl, int npoly, u32 fpmask) {
+  __shared__ u64 lds_raw[lds_words(LB)];
+  const int nlo = nl - 1;
+  const unsigned per = 8u * (unsigned)nlo;
+  const unsigned grp = blockIdx.x / per, rem = blockIdx.x % per;
+  const unsigned left = (unsigned)npoly - grp * 8u, gsz = left < 8u ? left : 8u;  // the last group may be ragged
+  const int j = (int)(rem / gsz);
+  const size_t p = (size_t)grp * 8 + rem % gsz;
+  const size_t N = (size_t)1 << LB;
+  const Mod mi = c.mods[j];
+  const u64 half = c.mods[nl - 1].q >> 1;
+  const u64 hm = reduce64(half, mi);
+  const u64 fixu = hm ? mi.q - hm : 0;
+  const u64 *__restrict__ src = last + p * N;
+  const u64 *__restrict__ x = in + (p * nl + j) * N;
+  u64 *__restrict__ o = out + (p * nlo + j) * N;
+  if ((fpmask >> j) & 1u) {  // workgroup-uniform
+    const Mod m = mod_at(c, j);
+    const FpTable t = fp_table(c, j);
+    const double inv = c.cst->inv_qlast_c[nl - 1][j], inv_q = c.cst->inv_qlast_cq[nl - 1][j];
+    // the dropped prime may be wider than 2^52: reduce modulo q_j as an integer first (canonical, + fix, below 2 q_j)
+    ntt_fwd_block_a<LB, FpArith>(
+        reinterpret_cast<double *>(lds_raw), [&](int, int i) { return fp_from_u64(add_mod(reduce64(src[i], mi), fixu, mi.q)); },
+        [&](int, int i, double v) { o[i] = fp_to_canon(fp_mul_lazy(fp_from_u64(x[i]) - v, inv, inv_q, m.qd), m.qd, m.qinv); }, t, m, 0, 0);
+  } else {
+    const NttTable t = ntt_table(c, j);
+    const u64 inv = c.cst->inv_qlast[nl - 1][j], inv_s = c.cst->inv_qlast_s[nl - 1][j];
+    ntt_fwd_block<LB, true>(
+        lds_raw, [&](int, int i) { return add_mod(reduce64(src[i], mi), fixu, mi.q); },
+        [&](int, int i, u64 v) { o[i] = mul_shoup(sub_mod(x[i], canon_fwd<true>(v, mi), mi.q), inv, inv_s, mi.q); }, t, mi, 0, 0);
+  }
+}
+template <int LB>
+static int launch_rescale_mixed(abc_hip_ctx *c, const u64 *in, u64 *out, int nl, size_t polys) {
+  const size_t N = (size_t)1 << LB;
+  if (ensure_workspace(c, polys * N * 8)) return 1;
+  u64 *last = (u64 *)c->ws;
+  u32 fpmask = 0;
+  if (c->use_fp && !c->sw.no_mixed)
+    for (int j = 0; j < nl; j++)
+      if (fp_ok(c->h_mods[j].bits)) fpmask |= 1u << j;
+  const dim3 block((1 << LB) / 16);
+  hipLaunchKernelGGL(k_rescale_intt_mixed<LB>, dim3((unsigned)polys), block, 0, c->stream, c->dc, in, last, nl, (int)((fpmask >> (nl - 1)) & 1u));
+  hipLaunchKernelGGL(k_rescale_ntt_mixed<LB>, dim3((unsigned)(polys * (nl - 1))), block, 0, c->stream, c->dc, in, last, out, nl, (int)polys,
+                     fpmask);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int launch_rescale(abc_hip_ctx *c, const u64 *in, u64 *out, int size, int nl, size_t count) {
   if (nl < 2) { set_error("rescale: no limb left to drop"); return 1; }
   const size_t N = (size_t)c->n, polys = count * size;
   if (!polys) return 0;
   bool fp = c->use_fp && c->logn <= 14 && in != out && !c->sw.no_fused;
   for (int j = 0; j < nl; j++) fp = fp && fp_ok(c->h_mods[j].bits);
+  if (!fp && c->logn <= 14 && in != out && !c->sw.no_fused && !c->sw.no_isplit) switch (c->logn) {  // a prime above 2^50 in the chain
+      case 10: return launch_rescale_mixed<10>(c, in, out, nl, polys);
+      case 11: return launch_rescale_mixed<11>(c, in, out, nl, polys);
+      case 12: return launch_rescale_mixed<12>(c, in, out, nl, polys);
+      case 13: return launch_rescale_mixed<13>(c, in, out, nl, polys);
+      case 14: return launch_rescale_mixed<14>(c, in, out, nl, polys);
+      default: break;
+    }
   if (fp) switch (c->logn) {
       case 10: return launch_rescale_fp<10>(c, in, out, nl, polys);
       case 11: return launch_rescale_fp<11>(c, in, out, nl, polys);
