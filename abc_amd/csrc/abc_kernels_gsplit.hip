@@ -285,7 +285,7 @@ struct GPairOps {
 };
 
 template <int LOGN, int MODE, bool GAL, int NL>
-__global__ __launch_bounds__(512, 4) void k_gsplit_main(DevCtx c, const double *__restrict__ part, const double *__restrict__ tpart,
+__global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_gsplit_main(DevCtx c, const double *__restrict__ part, const double *__restrict__ tpart,
                                                         const u64 *__restrict__ opa, const u64 *__restrict__ opb, size_t opa_stride,
                                                         size_t opb_stride, int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out,
                                                         u32 gelt, u32 imap, int ni) {
@@ -446,7 +446,10 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     case 1: ABC_GSP(1); break;
     case 2: ABC_GSP(2); break;
     case 3: ABC_GSP(3); break;
-    default: ABC_GSP(4); break;
+    case 4: ABC_GSP(4); break;
+    case 5: ABC_GSP(5); break;
+    case 6: ABC_GSP(6); break;
+    default: ABC_GSP(7); break;
   }
 #undef ABC_GSP
 }
@@ -455,7 +458,7 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
 bool gsplit_main_subset15(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const double *part, const double *tpart, const u64 *opa,
                           const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt, u32 imap,
                           int ni) {
-  if (nl < 1 || nl > 4 || ni < 1) return ni == 0;
+  if (nl < 1 || nl > 7 || ni < 1) return ni == 0;
   const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
   const dim3 gmain((unsigned)(cc * ni * 32));
 #define ABC_GSUB(NLV)                                                                                                                  \
@@ -472,7 +475,10 @@ bool gsplit_main_subset15(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int
     case 1: ABC_GSUB(1); break;
     case 2: ABC_GSUB(2); break;
     case 3: ABC_GSUB(3); break;
-    default: ABC_GSUB(4); break;
+    case 4: ABC_GSUB(4); break;
+    case 5: ABC_GSUB(5); break;
+    case 6: ABC_GSUB(6); break;
+    default: ABC_GSUB(7); break;
   }
 #undef ABC_GSUB
   return true;
@@ -483,7 +489,7 @@ size_t gsplit_scratch_words(const abc_hip_ctx *c, int nl) {
   return ((size_t)nl + (size_t)nl * (nl + 1) + 2 * (size_t)nl + 2) * (size_t)c->dc.ps;
 }
 bool gsplit_applies(const abc_hip_ctx *c, int nl) {
-  if (c->logn != 15 || c->scheme != 2 || !c->use_fp || c->sw.no_gsplit || nl < 1 || nl > 4) return false;
+  if (c->logn != 15 || c->scheme != 2 || !c->use_fp || c->sw.no_gsplit || nl < 1 || nl > 7) return false;
   for (int j = 0; j < c->K; j++)
     if (!fp_ok(c->h_mods[j].bits)) return false;
   return true;

@@ -526,7 +526,7 @@ size_t isplit_scratch_words(const abc_hip_ctx *c, int nl) {
 bool isplit_applies(const abc_hip_ctx *c, int nl) {
   if ((c->logn != 14 && c->logn != 15) || c->scheme != 2 || c->sw.no_fused || c->sw.no_split || c->sw.no_isplit || nl < 1 || nl > 7)
     return false;
-  if (c->logn == 15 && (nl > 4 || c->sw.no_gsplit)) return false;  // 32 blocks: instantiated for the chains of configs 3-4 depth
+  if (c->logn == 15 && c->sw.no_gsplit) return false;  // one switch turns both split sequences of that ring off (A/B, tests)
   for (int j = 0; j < c->K; j++)
     if (c->h_mods[j].bits > 60) return false;
   return true;
