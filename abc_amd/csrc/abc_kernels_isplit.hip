@@ -29,6 +29,7 @@ __device__ __forceinline__ double i_fp_mulmod(double x, double y, double q, doub
 // stages of a forward transform / the last R of an inverse one, in the arithmetic A of the prime (integer or fp64)
 template <int R, class A>
 __device__ __forceinline__ void x_fwd_cross(typename A::E (&x)[1 << R], const typename A::Table &t, const typename A::K &kk) {
+  static_assert(R <= 5, "at R = 6 the integer butterflies are left in a rolled stage loop and the array goes to scratch memory");
 #pragma unroll
   for (int u = 0; u < R; u++) {
     const int half = 1 << (R - 1 - u);
@@ -41,6 +42,7 @@ __device__ __forceinline__ void x_fwd_cross(typename A::E (&x)[1 << R], const ty
 }
 template <int R, class A>
 __device__ __forceinline__ void x_inv_cross(typename A::E (&x)[1 << R], const typename A::Table &t, const typename A::K &kk) {
+  static_assert(R <= 5, "see x_fwd_cross");
 #pragma unroll
   for (int u = R - 1; u >= 0; u--) {
     const int half = 1 << (R - 1 - u);
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(256) void k_igsplit_cross(DevCtx c, const u64 *__re
     }
     const NttTable t = ntt_table(c, ki);
     const typename A::K kk = A::consts(mI);
-    const bool need_reduce = GUARD ? (m.q > mI.q) : ((m.q >> 3) >= mI.q);  // as k_isplit_pass0
+    // unguarded: 4 q per stage over LOGN stages on top of the input must stay below 64 q -- input below 2 q_I at 15 stages
+    const bool need_reduce = GUARD ? (m.q > mI.q) : ((m.q >> (LOGN == 14 ? 3 : 1)) >= mI.q);
     u64 y[NB];
     if (need_reduce) {
 #pragma unroll
@@ -579,5 +582,6 @@ int isplit_chunk(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl
   ABC_HIP_CHECK(hipGetLastError());
   return 0;
 }
+
 
 }  // namespace abc
