@@ -117,12 +117,16 @@ int main(int argc, char **argv) {
   if (argc > 1 && std::string(argv[1]) == "cpu") return t.summary();
 
   const uint64_t seed = 0xABC00C55ull;
-  // ---- config 3 parameters: N = 2^14, {50,40,40,40 | 50}, scale 2^40 ----
-  {
+  // ---- config 3 parameters: N = 2^14, {50,40,40,40 | 50}, scale 2^40; then the same on a SEAL-typical {60,40,40,40 | 60} chain
+  //      (60-bit primes: integer kernels for their limbs, fp64 ones for the limbs between -- the plugin classes see no difference)
+  const std::vector<std::vector<int>> chains = {{50, 40, 40, 40, 50}, {60, 40, 40, 40, 60}};
+  for (const auto &bits : chains) {
+    const std::string tag = bits[0] == 50 ? "" : " [60-bit chain]";
     HipSchemeConfig cfg;
     cfg.ckks = true;
     cfg.ringDegree = 16384;
     cfg.seed = seed;
+    cfg.ckksBits = bits;
     HipCiphertextFactory f(cfg);
     Oracle o(14, cfg.ckksBits, seed);
     const size_t slots = 8192;
@@ -132,7 +136,7 @@ int main(int argc, char **argv) {
     for (auto &v : x) v = dist(rng);
     for (auto &v : y) v = dist(rng);
 
-    t.run("CKKS create / decrypt, add, subtract", [&] {
+    t.run(("CKKS create / decrypt, add, subtract" + tag).c_str(), [&] {
       auto a = f.createCiphertext(x), b = f.createCiphertext(y);
       EXPECT_TRUE(hip(*a).level() == 4);
       std::vector<double> got, want(slots);
@@ -147,7 +151,7 @@ int main(int argc, char **argv) {
       f.decryptCiphertextReal(*a->subtract(*b), got);
       expectClose(got, want, 1e-6, "subtract");
     });
-    t.run("CKKS multiply = mul + relinearise + rescale, residues equal to the oracle's at every level", [&] {
+    t.run(("CKKS multiply = mul + relinearise + rescale, residues equal to the oracle's at every level" + tag).c_str(), [&] {
       auto a = f.createCiphertext(x), b = f.createCiphertext(y);
       std::vector<double> want(x);
       for (int level = 4; level >= 2; --level) {
@@ -169,7 +173,7 @@ int main(int argc, char **argv) {
       }
       EXPECT_TRUE(hip(*b).level() == 4);  // operand untouched
     });
-    t.run("CKKS plain operands and rotation", [&] {
+    t.run(("CKKS plain operands and rotation" + tag).c_str(), [&] {
       auto a = f.createCiphertext(x);
       std::vector<double> got, want(slots);
       Cleartext<double> half(std::vector<double>{0.5});
