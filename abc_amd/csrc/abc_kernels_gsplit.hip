@@ -220,6 +220,10 @@ __global__ __launch_bounds__(NL * 64, (ALL && NL == 8) ? 4 : 1) void k_gsplit_sp
       s0[1] += g_mulmod(v.y, fp_from_u64(k0.y), q, qinv);
       s1[0] += g_mulmod(v.x, fp_from_u64(k1.x), q, qinv);
       s1[1] += g_mulmod(v.y, fp_from_u64(k1.y), q, qinv);
+      if (NL > 8 && (Jx & 7) == 7) {  // eight products of magnitude < q stay below 2^53; re-centre before adding more
+        s0[0] = fp_centre(s0[0], q, qinv); s0[1] = fp_centre(s0[1], q, qinv);
+        s1[0] = fp_centre(s1[0], q, qinv); s1[1] = fp_centre(s1[1], q, qinv);
+      }
     }
     f64x2 r;
     r.x = fp_centre(s0[0], q, qinv); r.y = fp_centre(s0[1], q, qinv);
@@ -401,6 +405,117 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_gsplit_main(DevCtx c, 
   *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
 }
 
+// ---- G2c for deep chains (8 to 15 data limbs): 1024 threads, one wavefront per limb (nl - 1 decomposition limbs + the two
+// mod-down limbs), one workgroup per CU (up to 152 KiB of LDS), key words loaded inside the sum instead of ahead of the transform
+// (16 x 16 bytes per limb would not fit the registers).  Same arithmetic, same buffers as k_gsplit_main.
+template <int LOGN, int MODE, bool GAL>
+__global__ __launch_bounds__(1024) void k_gsplit_main_deep(DevCtx c, const double *__restrict__ part, const double *__restrict__ tpart,
+                                                           const u64 *__restrict__ opa, const u64 *__restrict__ opb, size_t opa_stride,
+                                                           size_t opb_stride, int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out,
+                                                           u32 gelt, int nl) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, NT = 1024;
+  extern __shared__ double dyn[];
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & (NB - 1);
+  const int I = (int)((blockIdx.x >> LOGNB) % (unsigned)nl);
+  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)nl);
+  const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps;
+  const Mod m = mod_at(c, I);
+  const FpTable t = fp_table(c, I);
+  const double q = m.qd, qinv = m.qinv;
+  f64x2 *ltw = reinterpret_cast<f64x2 *>(dyn + (nl + 1) * lds_words(10));
+  const size_t pw = (size_t)nl * N;
+  const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
+  const double inv = cst->inv_special_c[I], inv_q = cst->inv_special_cq[I];
+  f64x2 twv[1];
+  block_twiddles_fetch<10, f64x2, 1>(t.tw, LOGNB, blk, (int)threadIdx.x, NT, twv);
+  const bool has_limb = W <= nl;
+  const int Wc = has_limb ? W : 0;
+  const double *__restrict__ src = (Wc < nl - 1) ? part + ((ct * (nl + 1) + I) * nl + (Wc < I ? Wc : Wc + 1)) * PS + base
+                                                 : tpart + ((ct * 2 + (Wc - (nl - 1))) * nl + I) * PS + base;
+  double xin[16];
+  if (has_limb) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const f64x2 v = *reinterpret_cast<const f64x2 *>(src + (k << 7) + 2 * lane);
+      xin[k] = v.x;
+      xin[8 + k] = v.y;
+    }
+  }
+  block_twiddles_store<10, f64x2, 1>(ltw, (int)threadIdx.x, NT, twv);
+  __syncthreads();
+  if (has_limb) {
+    double *buf = dyn + W * lds_words(10);
+    if (m.bits >= 49) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) xin[r] = fp_centre(xin[r], q, qinv);
+    }
+    ntt_fwd_tail1024_pairs<FpArith>(buf, xin, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, LOGNB, blk, lane, ltw);
+  }
+  __syncthreads();
+  if (threadIdx.x >= 512) return;  // one coefficient pair per thread of the first eight wavefronts
+  const int e = 2 * (int)threadIdx.x;
+  const double *tt0 = dyn + (nl - 1) * lds_words(10), *tt1 = dyn + nl * lds_words(10);
+  double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
+  for (int Jx = 0; Jx < nl; Jx++) {
+    double x[2];
+    if (Jx == I) {
+      if (MODE == 0) {
+        const u64 *pa = opa + ct * 2 * pw + (size_t)I * N + base + e, *pb = opb + ct * 2 * pw + (size_t)I * N + base + e;
+        const u64x2 a0 = *reinterpret_cast<const u64x2 *>(pa), a1 = *reinterpret_cast<const u64x2 *>(pa + pw);
+        const u64x2 b0 = *reinterpret_cast<const u64x2 *>(pb), b1 = *reinterpret_cast<const u64x2 *>(pb + pw);
+        const double x0[2] = {fp_from_u64(a0.x), fp_from_u64(a0.y)}, x1[2] = {fp_from_u64(a1.x), fp_from_u64(a1.y)};
+        const double y0[2] = {fp_from_u64(b0.x), fp_from_u64(b0.y)}, y1[2] = {fp_from_u64(b1.x), fp_from_u64(b1.y)};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          x[k] = g_mulmod(x1[k], y1[k], q, qinv);
+          d0[k] = g_mulmod(x0[k], y0[k], q, qinv);
+          d1[k] = g_mulmod(x0[k], y1[k], q, qinv) + g_mulmod(x1[k], y0[k], q, qinv);
+        }
+      } else {
+        const u64 *xl = opa + ct * opa_stride + (size_t)I * N;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const u32 si = galois_ntt_src<GAL>((u32)(base + e + k), gelt, LOGN);
+          x[k] = fp_from_u64(xl[si]);
+          if (opb) {
+            const u64 *ad = opb + ct * opb_stride + (size_t)I * N;
+            d0[k] = fp_from_u64(ad[si]);
+            if (add_c1) d1[k] = fp_from_u64(ad[pw + si]);
+          }
+        }
+      }
+    } else {
+      const int w = Jx < I ? Jx : Jx - 1;
+      const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + w * lds_words(10) + lds_pad(e));
+      x[0] = v.x;
+      x[1] = v.y;
+    }
+    const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + I) * N + base + e);
+    const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + I) * N + base + e);
+    s0[0] += g_mulmod(x[0], fp_from_u64(k0.x), q, qinv);
+    s0[1] += g_mulmod(x[1], fp_from_u64(k0.y), q, qinv);
+    s1[0] += g_mulmod(x[0], fp_from_u64(k1.x), q, qinv);
+    s1[1] += g_mulmod(x[1], fp_from_u64(k1.y), q, qinv);
+    if ((Jx & 7) == 7) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        s0[k] = fp_centre(s0[k], q, qinv);
+        s1[k] = fp_centre(s1[k], q, qinv);
+      }
+    }
+  }
+  const f64x2 u0 = *reinterpret_cast<const f64x2 *>(tt0 + lds_pad(e)), u1 = *reinterpret_cast<const f64x2 *>(tt1 + lds_pad(e));
+  u64x2 r;
+  r.x = fp_to_canon(fp_mul_lazy(s0[0] - u0.x, inv, inv_q, q) + d0[0], q, qinv);
+  r.y = fp_to_canon(fp_mul_lazy(s0[1] - u0.y, inv, inv_q, q) + d0[1], q, qinv);
+  *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 0) * nl + I) * N + base + e) = r;
+  r.x = fp_to_canon(fp_mul_lazy(s1[0] - u1.x, inv, inv_q, q) + d1[0], q, qinv);
+  r.y = fp_to_canon(fp_mul_lazy(s1[1] - u1.y, inv, inv_q, q) + d1[1], q, qinv);
+  *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
+}
+
 // ---- host side ----
 // first step only (the half-done decomposition limbs): used by the N = 2^14 sequence for small batches
 template <int LOGN>
@@ -430,6 +545,31 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   const size_t lds_sp = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
   const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
   const dim3 gsp((unsigned)(cc * NB)), gmain((unsigned)(cc * nl * NB));
+  if (nl > 7) {  // deep chains: one wavefront per limb still, but up to sixteen of them
+#define ABC_GSPD(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp, (int)cc)
+    switch (nl) {
+      case 8: ABC_GSPD(8); break;
+      case 9: ABC_GSPD(9); break;
+      case 10: ABC_GSPD(10); break;
+      case 11: ABC_GSPD(11); break;
+      case 12: ABC_GSPD(12); break;
+      case 13: ABC_GSPD(13); break;
+      case 14: ABC_GSPD(14); break;
+      default: ABC_GSPD(15); break;
+    }
+#undef ABC_GSPD
+    hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp, tpart, nl);
+    if (mode == 0)
+      hipLaunchKernelGGL((k_gsplit_main_deep<LOGN, 0, false>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
+                         opb_stride, add_c1, key, out, gelt, nl);
+    else if (gelt)
+      hipLaunchKernelGGL((k_gsplit_main_deep<LOGN, 1, true>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
+                         opb_stride, add_c1, key, out, gelt, nl);
+    else
+      hipLaunchKernelGGL((k_gsplit_main_deep<LOGN, 1, false>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
+                         opb_stride, add_c1, key, out, gelt, nl);
+    return;
+  }
 #define ABC_GSP(NLV)                                                                                                                    \
   hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp, (int)cc);                            \
   hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp, tpart, nl);                     \
@@ -489,7 +629,7 @@ size_t gsplit_scratch_words(const abc_hip_ctx *c, int nl) {
   return ((size_t)nl + (size_t)nl * (nl + 1) + 2 * (size_t)nl + 2) * (size_t)c->dc.ps;
 }
 bool gsplit_applies(const abc_hip_ctx *c, int nl) {
-  if (c->logn != 15 || c->scheme != 2 || !c->use_fp || c->sw.no_gsplit || nl < 1 || nl > 7) return false;
+  if (c->logn != 15 || c->scheme != 2 || !c->use_fp || c->sw.no_gsplit || nl < 1 || nl > 15) return false;
   for (int j = 0; j < c->K; j++)
     if (!fp_ok(c->h_mods[j].bits)) return false;
   return true;
