@@ -247,6 +247,9 @@ bool split4_main_subset(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int m
 bool gsplit_main_subset15(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const double *part, const double *tpart, const u64 *opa,
                           const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt, u32 imap,
                           int ni);
+void gsplit_main_deep_subset15(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const double *part, const double *tpart,
+                               const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out,
+                               u32 gelt, u64 imap, int ni);
 bool bsplit_applies(const abc_hip_ctx *c, int nl);
 bool bsplit_big_applies(const abc_hip_ctx *c, int nl);
 int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count, const u64 *addend,

@@ -412,14 +412,15 @@ template <int LOGN, int MODE, bool GAL>
 __global__ __launch_bounds__(1024) void k_gsplit_main_deep(DevCtx c, const double *__restrict__ part, const double *__restrict__ tpart,
                                                            const u64 *__restrict__ opa, const u64 *__restrict__ opb, size_t opa_stride,
                                                            size_t opb_stride, int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out,
-                                                           u32 gelt, int nl) {
+                                                           u32 gelt, int nl, u64 imap, int ni) {
+  // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all: 0xfedcba9876543210, ni = nl)
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, NT = 1024;
   extern __shared__ double dyn[];
   const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int blk = blockIdx.x & (NB - 1);
-  const int I = (int)((blockIdx.x >> LOGNB) % (unsigned)nl);
-  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)nl);
+  const int I = (int)((imap >> (4 * ((blockIdx.x >> LOGNB) % (unsigned)ni))) & 15u);
+  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)ni);
   const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps;
   const Mod m = mod_at(c, I);
   const FpTable t = fp_table(c, I);
@@ -561,13 +562,13 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp, tpart, nl);
     if (mode == 0)
       hipLaunchKernelGGL((k_gsplit_main_deep<LOGN, 0, false>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
-                         opb_stride, add_c1, key, out, gelt, nl);
+                         opb_stride, add_c1, key, out, gelt, nl, 0xfedcba9876543210ull, nl);
     else if (gelt)
       hipLaunchKernelGGL((k_gsplit_main_deep<LOGN, 1, true>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
-                         opb_stride, add_c1, key, out, gelt, nl);
+                         opb_stride, add_c1, key, out, gelt, nl, 0xfedcba9876543210ull, nl);
     else
       hipLaunchKernelGGL((k_gsplit_main_deep<LOGN, 1, false>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
-                         opb_stride, add_c1, key, out, gelt, nl);
+                         opb_stride, add_c1, key, out, gelt, nl, 0xfedcba9876543210ull, nl);
     return;
   }
 #define ABC_GSP(NLV)                                                                                                                    \
@@ -592,6 +593,24 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     default: ABC_GSP(7); break;
   }
 #undef ABC_GSP
+}
+
+// the deep-chain main step of N = 2^15 over a subset of the data primes (mixed chains of 8 to 15 limbs, abc_kernels_isplit.hip)
+void gsplit_main_deep_subset15(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const double *part, const double *tpart,
+                               const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out,
+                               u32 gelt, u64 imap, int ni) {
+  if (ni < 1) return;
+  const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
+  const dim3 gmain((unsigned)(cc * ni * 32));
+  if (mode == 0)
+    hipLaunchKernelGGL((k_gsplit_main_deep<15, 0, false>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, opb_stride,
+                       add_c1, key, out, gelt, nl, imap, ni);
+  else if (gelt)
+    hipLaunchKernelGGL((k_gsplit_main_deep<15, 1, true>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, opb_stride,
+                       add_c1, key, out, gelt, nl, imap, ni);
+  else
+    hipLaunchKernelGGL((k_gsplit_main_deep<15, 1, false>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride, opb_stride,
+                       add_c1, key, out, gelt, nl, imap, ni);
 }
 
 // the main step of N = 2^15 over a subset of the data primes (mixed chains, abc_kernels_isplit.hip): mode 0 multiply, mode 1 key switch

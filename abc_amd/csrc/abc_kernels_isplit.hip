@@ -473,6 +473,160 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_isplit_main(DevCtx c, 
   *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = u64x2{r1[0], r1[1]};
 }
 
+// K2c for deep chains (8 to 15 data limbs; cf. k_gsplit_main_deep): sixteen wavefronts, one per limb, key words loaded inside the sum
+template <int MODE, bool GAL, bool GUARD, int LOGN>
+__global__ __launch_bounds__(1024) void k_isplit_main_deep(DevCtx c, const u64 *__restrict__ part, const u64 *__restrict__ tpart,
+                                                           const u64 *__restrict__ opa, const u64 *__restrict__ opb, size_t opa_stride,
+                                                           size_t opb_stride, int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out,
+                                                           u32 gelt, int nl, u64 imap, int ni) {
+  extern __shared__ u64 dynu[];  // nl + 1 transform buffers, then the block's twiddle table
+  constexpr int NT = 1024, LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  using A = IntArith<GUARD>;
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & (NB - 1);
+  const int I = (int)((imap >> (4 * ((blockIdx.x >> LOGNB) % (unsigned)ni))) & 15u);
+  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)ni);
+  const size_t N = (size_t)c.n, base = (size_t)blk << 10, PS = (size_t)c.ps;
+  const Mod m = c.mods[I];
+  const NttTable t = ntt_table(c, I);
+  u64x2 *ltw = reinterpret_cast<u64x2 *>(dynu + (nl + 1) * lds_words(10));
+  const size_t pw = (size_t)nl * N;
+  const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
+  const u64 sp = cst->special_mod_q[I], sp_s = cst->special_mod_q_s[I];
+  const u64 inv = cst->inv_special[I], inv_s = cst->inv_special_s[I];
+  u64x2 twv[1];
+  block_twiddles_fetch_g<10, u64x2, 1>(t.tw, LOGNB, blk, (int)threadIdx.x, NT, twv);
+  const bool has_limb = W <= nl;
+  const int Wc = has_limb ? W : 0;
+  const u64 *__restrict__ src = (Wc < nl - 1) ? part + ((ct * (nl + 1) + I) * nl + (Wc < I ? Wc : Wc + 1)) * PS + base
+                                              : tpart + ((ct * 2 + (Wc - (nl - 1))) * nl + I) * PS + base;
+  u64 xin[16];
+  if (has_limb) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const u64x2 v = *reinterpret_cast<const u64x2 *>(src + (k << 7) + 2 * lane);
+      xin[k] = v.x;
+      xin[8 + k] = v.y;
+    }
+  }
+  block_twiddles_store<10, u64x2, 1>(ltw, (int)threadIdx.x, NT, twv);
+  __syncthreads();
+  if (has_limb) {
+    u64 *buf = dynu + W * lds_words(10);
+    ntt_fwd_tail1024_pairs<A>(buf, xin, [&](int, int i, u64 v) { buf[lds_pad(i)] = canon_fwd<GUARD>(v, m); }, t, m, LOGNB, blk, lane, ltw);
+  }
+  __syncthreads();
+  if (threadIdx.x >= 512) return;
+  const int e = 2 * (int)threadIdx.x;
+  const u64 *tt0 = dynu + (nl - 1) * lds_words(10), *tt1 = dynu + nl * lds_words(10);
+  U128 s0[2] = {{0, 0}, {0, 0}}, s1[2] = {{0, 0}, {0, 0}};
+  u64 d0[2] = {0, 0}, d1[2] = {0, 0};
+  for (int Jx = 0; Jx < nl; Jx++) {
+    u64 x[2];
+    if (Jx == I) {
+      if (MODE == 0) {
+        const u64 *pa = opa + ct * 2 * pw + (size_t)I * N + base + e, *pb = opb + ct * 2 * pw + (size_t)I * N + base + e;
+        const u64x2 a0 = *reinterpret_cast<const u64x2 *>(pa), a1 = *reinterpret_cast<const u64x2 *>(pa + pw);
+        const u64x2 b0 = *reinterpret_cast<const u64x2 *>(pb), b1 = *reinterpret_cast<const u64x2 *>(pb + pw);
+        const u64 x0[2] = {a0.x, a0.y}, x1[2] = {a1.x, a1.y}, y0[2] = {b0.x, b0.y}, y1[2] = {b1.x, b1.y};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          x[k] = mul_mod(x1[k], y1[k], m);
+          d0[k] = mul_mod(x0[k], y0[k], m);
+          U128 acc = mul_wide(x0[k], y1[k]);
+          mac128(acc, x1[k], y0[k]);
+          d1[k] = barrett_reduce(acc, m);
+        }
+      } else {
+        const u64 *xl = opa + ct * opa_stride + (size_t)I * N;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const u32 si = galois_ntt_src<GAL>((u32)(base + e + k), gelt, c.logn);
+          x[k] = xl[si];
+          if (opb) {
+            const u64 *ad = opb + ct * opb_stride + (size_t)I * N;
+            d0[k] = ad[si];
+            if (add_c1) d1[k] = ad[pw + si];
+          }
+        }
+      }
+    } else {
+      const int w = Jx < I ? Jx : Jx - 1;
+      const u64x2 v = *reinterpret_cast<const u64x2 *>(dynu + w * lds_words(10) + lds_pad(e));
+      x[0] = v.x;
+      x[1] = v.y;
+    }
+    const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + I) * N + base + e);
+    const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + I) * N + base + e);
+    mac128(s0[0], x[0], k0.x); mac128(s0[1], x[1], k0.y);
+    mac128(s1[0], x[0], k1.x); mac128(s1[1], x[1], k1.y);
+    if ((Jx & 3) == 3) {  // four products of canonical operands per 128-bit accumulator
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        s0[k] = U128{barrett_reduce(s0[k], m), 0};
+        s1[k] = U128{barrett_reduce(s1[k], m), 0};
+      }
+    }
+  }
+  const u64x2 u0 = *reinterpret_cast<const u64x2 *>(tt0 + lds_pad(e)), u1 = *reinterpret_cast<const u64x2 *>(tt1 + lds_pad(e));
+  const u64 t0[2] = {u0.x, u0.y}, t1[2] = {u1.x, u1.y};
+  u64 r0[2], r1[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const u64 a0v = add_mod(barrett_reduce(s0[k], m), mul_shoup(d0[k], sp, sp_s, m.q), m.q);
+    const u64 a1v = add_mod(barrett_reduce(s1[k], m), mul_shoup(d1[k], sp, sp_s, m.q), m.q);
+    r0[k] = mul_shoup(sub_mod(a0v, t0[k], m.q), inv, inv_s, m.q);
+    r1[k] = mul_shoup(sub_mod(a1v, t1[k], m.q), inv, inv_s, m.q);
+  }
+  *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 0) * nl + I) * N + base + e) = u64x2{r0[0], r0[1]};
+  *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = u64x2{r1[0], r1[1]};
+}
+
+// steps 2-4 of a deep chain at N = 2^15: special prime (integer), register pass, then the last step per arithmetic class
+template <bool GUARD>
+static void launch_isplit_tail_deep15(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, u64 *part, u64 *tpart, u64 *tsp_half, int mode,
+                                      const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key,
+                                      u64 *out, u32 gelt, u32 fpmask) {
+  const size_t lds_sp = (size_t)(nl * lds_words(10)) * 8;
+  const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
+  u64 imap_int = 0, imap_fp = 0;
+  int ni_int = 0, ni_fp = 0;
+  for (int I = 0; I < nl; I++) {
+    if ((fpmask >> I) & 1u) imap_fp |= (u64)I << (4 * ni_fp++);
+    else imap_int |= (u64)I << (4 * ni_int++);
+  }
+  const dim3 gsp((unsigned)(cc * 32));
+#define ABC_ISPD(NLV) hipLaunchKernelGGL((k_isplit_special<GUARD, NLV, 15>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp_half)
+  switch (nl) {
+    case 8: ABC_ISPD(8); break;
+    case 9: ABC_ISPD(9); break;
+    case 10: ABC_ISPD(10); break;
+    case 11: ABC_ISPD(11); break;
+    case 12: ABC_ISPD(12); break;
+    case 13: ABC_ISPD(13); break;
+    case 14: ABC_ISPD(14); break;
+    default: ABC_ISPD(15); break;
+  }
+#undef ABC_ISPD
+  hipLaunchKernelGGL((k_isplit_pass<15, GUARD>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp_half, tpart, nl, fpmask);
+  if (ni_int) {
+    const dim3 gmain((unsigned)(cc * ni_int * 32));
+    if (mode == 0)
+      hipLaunchKernelGGL((k_isplit_main_deep<0, false, GUARD, 15>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
+                         opb_stride, add_c1, key, out, gelt, nl, imap_int, ni_int);
+    else if (gelt)
+      hipLaunchKernelGGL((k_isplit_main_deep<1, true, GUARD, 15>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
+                         opb_stride, add_c1, key, out, gelt, nl, imap_int, ni_int);
+    else
+      hipLaunchKernelGGL((k_isplit_main_deep<1, false, GUARD, 15>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
+                         opb_stride, add_c1, key, out, gelt, nl, imap_int, ni_int);
+  }
+  if (ni_fp)
+    gsplit_main_deep_subset15(st, c, cc, nl, mode, (const double *)part, (const double *)tpart, opa, opb, opa_stride, opb_stride, add_c1, key,
+                              out, gelt, imap_fp, ni_fp);
+}
+
 // ---- launch sequence on one chunk ----
 template <bool GUARD, int LOGN>
 static void launch_isplit_tail(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, u64 *part, u64 *tpart, u64 *tsp_half, int mode,
@@ -527,7 +681,8 @@ size_t isplit_scratch_words(const abc_hip_ctx *c, int nl) {
 }
 
 bool isplit_applies(const abc_hip_ctx *c, int nl) {
-  if ((c->logn != 14 && c->logn != 15) || c->scheme != 2 || c->sw.no_fused || c->sw.no_split || c->sw.no_isplit || nl < 1 || nl > 7)
+  if ((c->logn != 14 && c->logn != 15) || c->scheme != 2 || c->sw.no_fused || c->sw.no_split || c->sw.no_isplit || nl < 1 ||
+      nl > (c->logn == 15 ? 15 : 7))
     return false;
   if (c->logn == 15 && c->sw.no_gsplit) return false;  // one switch turns both split sequences of that ring off (A/B, tests)
   for (int j = 0; j < c->K; j++)
@@ -557,6 +712,17 @@ int isplit_chunk(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl
       hipLaunchKernelGGL((k_igsplit_inv_tails<15, 1, true>), ga, dim3(256), lds, st, c->dc, opa, nullptr, opa_stride, hinv, nl, (int)cc, gelt);
     else
       hipLaunchKernelGGL((k_igsplit_inv_tails<15, 1, false>), ga, dim3(256), lds, st, c->dc, opa, nullptr, opa_stride, hinv, nl, (int)cc, 0u);
+    if (nl > 7) {
+      if (guard) {
+        hipLaunchKernelGGL((k_igsplit_cross<15, true>), gb, dim3(256), 0, st, c->dc, hinv, part, nl, fpmask);
+        launch_isplit_tail_deep15<true>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
+      } else {
+        hipLaunchKernelGGL((k_igsplit_cross<15, false>), gb, dim3(256), 0, st, c->dc, hinv, part, nl, fpmask);
+        launch_isplit_tail_deep15<false>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);
+      }
+      ABC_HIP_CHECK(hipGetLastError());
+      return 0;
+    }
     if (guard) {
       hipLaunchKernelGGL((k_igsplit_cross<15, true>), gb, dim3(256), 0, st, c->dc, hinv, part, nl, fpmask);
       launch_isplit_tail<true, 15>(st, c, cc, nl, part, tpart, tsp, mode, opa, opb, opa_stride, opb_stride, add_c1, key, out, gelt, fpmask);

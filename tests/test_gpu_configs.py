@@ -145,7 +145,8 @@ def test_bfv_default_8192_and_16384(oracle_mod, capi):
 
 @pytest.mark.parametrize("bits", [[50, 40, 40, 40, 50], [60, 40, 40, 40, 60], [57, 45, 45, 57], [50, 58, 40, 55],
                                   [50, 40, 40, 40, 40, 40, 50], [60, 45, 45, 45, 45, 45, 45, 60],
-                                  [50] + [40] * 8 + [50]])  # nine data limbs: the deep-chain main kernel (levels 9 and 8)
+                                  [50] + [40] * 8 + [50],   # nine data limbs: the deep-chain main kernel (levels 9 and 8)
+                                  [60] + [40] * 8 + [60]])  # the same depth on a SEAL-typical chain: integer + fp64 deep kernels
 @pytest.mark.parametrize("generic", [False, True, "integer_only"])
 def test_ckks15_every_level_split_and_generic(generic, bits, oracle_mod, capi, monkeypatch):
     """N = 2^15: the split key switch without LDS-resident limbs (abc_kernels_gsplit.hip) and the generic kernels it
