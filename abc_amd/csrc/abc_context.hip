@@ -34,6 +34,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_gsplit = env_on("ABC_HIP_NO_GSPLIT");
   s.no_bsplit = env_on("ABC_HIP_NO_BSPLIT");
   s.no_mixed = env_on("ABC_HIP_NO_MIXED");
+  s.no_pack = env_on("ABC_HIP_NO_PACK");
   s.no_lean_front = env_on("ABC_HIP_NO_LEAN_FRONT");
   s.split4_special = env_on("ABC_HIP_SPLIT4_SPECIAL");
   s.no_tensor_decomp = env_on("ABC_HIP_NO_TENSOR_DECOMP");

@@ -152,7 +152,7 @@ struct abc_hip_ctx {
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
   struct Switches {
-    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, no_bsplit = false, no_mixed = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
+    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, no_bsplit = false, no_mixed = false, no_pack = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
     bool tailmac_serial = false, no_galois_fusion = false;
     size_t chunk = 0, few_limbs = 48, bfv_scratch_mb = 0, pass0_target_limit = 128;
     int lanes = 2;
@@ -240,7 +240,7 @@ size_t gsplit_scratch_words(const abc_hip_ctx *c, int nl);
 int gsplit_chunk15(abc_hip_ctx *c, hipStream_t st, u64 *scratch, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb,
                    size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt);
 void gsplit_front14(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb, size_t opa_stride,
-                    double *hinv, double *part, u32 gelt);
+                    double *hinv, double *part, u32 gelt, int pack = 0);
 bool split4_main_subset(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const double *part, const double *tpart, const u64 *opa,
                         const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt, u32 imap,
                         int ni);

@@ -517,6 +517,24 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_decomp_fp(DevCt
   }
 }
 
+// the sixteen stride-2^(LB-4) values of a lane after the first register pass of a forward transform -> the half-done limb at dst,
+// raw doubles (kind 0) or centred and packed (abc_ntt.hpp, "packed half-done limbs"); kind is workgroup-uniform
+template <int LB>
+__device__ __forceinline__ void store_half_done(double *__restrict__ dst, double (&y)[16], int p, const FpK &kk, int kind) {
+  constexpr size_t N = (size_t)1 << LB;
+  constexpr int SH = LB - 4;
+  if (kind == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[(k << SH) + p] = y[k];
+  } else if (kind == 1) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) pack_store<1>(dst, N, (size_t)(k << SH) + p, fp_centre(y[k], kk.q, kk.qinv));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) pack_store<2>(dst, N, (size_t)(k << SH) + p, fp_centre(y[k], kk.q, kk.qinv));
+  }
+}
+
 // ---- split transforms (N = 2^14) ------------------------------------------------------------------------------------
 // A 2^14-point forward transform is a radix-16 pass over stride-1024 elements (stages 0..3, no LDS: the sixteen
 // operands of a lane are exactly what the inverse transform's last pass leaves in its registers) followed by
@@ -612,9 +630,8 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCt
 #pragma unroll
     for (int k = 0; k < 16; k++) y[k] = x[k];
     fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
-    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * (padded ? (size_t)c.ps : N);
-#pragma unroll
-    for (int k = 0; k < 16; k++) dst[(k << 10) + tid] = y[k];
+    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * ((padded & 1) ? (size_t)c.ps : N);
+    store_half_done<LB>(dst, y, tid, kk, ((padded & 2) && I < nl) ? pack_kind(m.bits) : 0);  // padded bit 1: packed (data primes only)
   }
 }
 
@@ -766,7 +783,7 @@ __global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const 
 template <int LB>
 __global__ __launch_bounds__((1 << LB) / 16) void k_split2_tensor_pass0_fp(DevCtx c, const u64 *__restrict__ a,
                                                                            const u64 *__restrict__ b, double *__restrict__ part,
-                                                                           int nl) {
+                                                                           int nl, int pack) {
   static_assert(LB == 14, "split transforms are laid out for N = 2^14");
   __shared__ double lds[lds_words(LB)];
   const int j = blockIdx.x % nl;
@@ -800,8 +817,7 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_split2_tensor_pass0_fp(DevCt
     for (int k = 0; k < 16; k++) y[k] = src[k];
     fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
     double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * (size_t)c.ps;
-#pragma unroll
-    for (int k = 0; k < 16; k++) dst[(k << 10) + tid] = y[k];
+    store_half_done<LB>(dst, y, tid, kk, (pack && I < nl) ? pack_kind(m.bits) : 0);  // the special prime's limbs stay raw
   }
 }
 
@@ -1025,7 +1041,8 @@ static inline FusedScratch carve(u64 *base, size_t chunk, int nl, size_t N) {
 //       and stores the result: the accumulators never leave the CU (8 + 8 limbs), and the 139 KiB mod-down workgroups,
 //       whose load / compute / store phases did not overlap at all (T = T_HBM + T_VALU), are gone.
 template <int LB>
-__global__ __launch_bounds__(256) void k_split3_pass_fp(DevCtx c, const double *__restrict__ tsp_half, double *__restrict__ tpart, int nl) {
+__global__ __launch_bounds__(256) void k_split3_pass_fp(DevCtx c, const double *__restrict__ tsp_half, double *__restrict__ tpart, int nl,
+                                                        int pack) {
   static_assert(LB == 14, "split transforms are laid out for N = 2^14");
   const size_t cc = blockIdx.x >> 2;                                  // ct*2 + comp
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;      // position inside every 1024-point block
@@ -1059,8 +1076,7 @@ __global__ __launch_bounds__(256) void k_split3_pass_fp(DevCtx c, const double *
     for (int k = 0; k < 16; k++) y[k] = x[k] + fix;
     fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
     double *__restrict__ dst = tpart + (cc * nl + j) * (size_t)c.ps;
-#pragma unroll
-    for (int k = 0; k < 16; k++) dst[(k << 10) + p] = y[k];
+    store_half_done<LB>(dst, y, p, kk, pack ? pack_kind(m.bits) : 0);
   }
 }
 
@@ -1200,9 +1216,10 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
                                                                    const double *__restrict__ tpart, const u64 *__restrict__ opa,
                                                                    const u64 *__restrict__ opb, size_t opa_stride, size_t opb_stride,
                                                                    int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out, u32 gelt,
-                                                                   u32 imap, int ni) {
+                                                                   u32 imap, int ni, int pack) {
   // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all of them: 0x76543210, ni = nl; a subset
   // when a chain mixes fp64-capable and wider primes: abc_kernels_isplit.hip)
+  // pack: the half-done limbs of `part` / `tpart` modulo primes of at most 48 bits arrive packed (abc_ntt.hpp)
   extern __shared__ double dyn[];  // nl + 1 transform buffers, then the block's twiddle table (1024 {w, w/q} pairs)
   // 512 threads whatever nl: one coefficient pair per thread afterwards, so every operand of that phase is requested up front;
   // wavefronts nl + 1 .. 7 have no limb to transform and only take part in the table fill and the inner product
@@ -1230,13 +1247,18 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
   const int Wc = has_limb ? W : 0;
   const double *__restrict__ src = (Wc < nl - 1) ? part + ((ct * (nl + 1) + I) * nl + (Wc < I ? Wc : Wc + 1)) * (size_t)c.ps + base
                                                  : tpart + ((ct * 2 + (Wc - (nl - 1))) * nl + I) * (size_t)c.ps + base;
-  double xin[16];
-  if (has_limb) {  // eight 16-byte loads: slot g*8 + k = element k*128 + 2*lane + g (ntt_fwd_tail1024_pairs)
+  const int pk = pack ? pack_kind(m.bits) : 0;  // workgroup-uniform
+  u64x2 raw[8];
+  if (has_limb) {  // eight loads of one coefficient pair: slot g*8 + k = element k*128 + 2*lane + g (ntt_fwd_tail1024_pairs)
+    if (pk == 0) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const f64x2 v = *reinterpret_cast<const f64x2 *>(src + (k << 7) + 2 * lane);
-      xin[k] = v.x;
-      xin[8 + k] = v.y;
+      for (int k = 0; k < 8; k++) raw[k] = *reinterpret_cast<const u64x2 *>(src + (k << 7) + 2 * lane);
+    } else if (pk == 1) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) raw[k] = pack_load_pair<1>(src - base, N, base + (k << 7) + 2 * lane);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) raw[k] = pack_load_pair<2>(src - base, N, base + (k << 7) + 2 * lane);
     }
   }
   auto load_pair = [&](int e, PairOps<MODE, NL> &o) {
@@ -1271,8 +1293,23 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
   __syncthreads();
   if (has_limb) {
     double *buf = dyn + W * lds_words(10);
-    // half-done limbs arrive below 4.1 q (four lazy stages from a canonical value): primes of 49 / 50 bits re-centre before the
-    // remaining ten stages, smaller ones have the headroom for all fourteen (abc_ntt.hpp, FpK::red) -- wavefront-uniform branch
+    double xin[16];
+    if (pk == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        xin[k] = __longlong_as_double((long long)raw[k].x);
+        xin[8 + k] = __longlong_as_double((long long)raw[k].y);
+      }
+    } else if (pk == 1) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) pack_decode_pair<1>(raw[k], xin[k], xin[8 + k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) pack_decode_pair<2>(raw[k], xin[k], xin[8 + k]);
+    }
+    // raw half-done limbs arrive below 4.1 q (four lazy stages from a canonical value): primes of 49 / 50 bits re-centre before
+    // the remaining ten stages, smaller ones have the headroom for all fourteen (abc_ntt.hpp, FpK::red); packed ones arrive
+    // centred -- wavefront-uniform branch
     if (m.bits >= 49) {
 #pragma unroll
       for (int r = 0; r < 16; r++) xin[r] = fp_centre(xin[r], q, qinv);
@@ -1337,7 +1374,7 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
 template <int MODE, bool GAL>
 static bool launch_split4_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const double *tpart, const u64 *opa,
                                const u64 *opb, size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt,
-                               u32 imap = 0x76543210u, int ni = -1) {
+                               u32 imap = 0x76543210u, int ni = -1, int pack = 0) {
   if (nl < 1 || nl > 7) return false;  // nl + 1 transform buffers of 8.5 KiB + the table: two workgroups per CU up to nl = 6, one at 7
   if (ni < 0) ni = nl;
   if (ni == 0) return true;
@@ -1345,7 +1382,7 @@ static bool launch_split4_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   const size_t lds = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
 #define ABC_TM4(NLV)                                                                                                                 \
   hipLaunchKernelGGL((k_split4_main_fp<MODE, GAL, NLV>), grid, block, lds, st, c->dc, part, tpart, opa, opb, opa_stride, opb_stride, \
-                     add_c1, key, out, gelt, imap, ni)
+                     add_c1, key, out, gelt, imap, ni, pack)
   switch (nl) {
     case 1: ABC_TM4(1); break;
     case 2: ABC_TM4(2); break;
@@ -1461,23 +1498,27 @@ static bool launch_split4_special(hipStream_t st, abc_hip_ctx *c, size_t cc, int
 // K2a..K2c on one chunk (the half-done decomposition limbs are in s.dec)
 template <int MODE, bool GAL>
 static void launch_split3(hipStream_t st, abc_hip_ctx *c, const FusedScratch &s, size_t cc, int nl, const u64 *opa, const u64 *opb,
-                          size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt) {
+                          size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt, int pack) {
   // (k_split4_special_fp, the LDS-table twin of the special-prime workgroups, measured 9 % slower than this: two tables to
   // fill for four transforms; kept behind ABC_HIP_SPLIT4_SPECIAL=1 for A/B)
   if (!c->sw.split4_special || !launch_split4_special(st, c, cc, nl, (const double *)s.dec, key, (double *)s.tsp))
     launch_split2_tailmac<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, opa, opb, opa_stride, opb_stride, add_c1, key, s.ksacc,
                                      (double *)s.tsp, gelt, 1);
   hipLaunchKernelGGL(k_split3_pass_fp<14>, dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, (const double *)s.tsp, (double *)s.ksacc,
-                     nl);
+                     nl, pack);
   // (measured at nl = 5 / 6 / 7, every prime below 2^50: +9.5 / -5 / -14 % against k_split3_main_fp: above five limbs the prefetched
   // key words push the kernel past 128 VGPRs and to one workgroup per CU)
   if (!c->sw.no_split4 && nl <= 5 && launch_split4_main<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, (const double *)s.ksacc, opa, opb,
-                                                        opa_stride, opb_stride, add_c1, key, out, gelt))
+                                                        opa_stride, opb_stride, add_c1, key, out, gelt, 0x76543210u, -1, pack))
     return;
   launch_split3_main<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, (const double *)s.ksacc, opa, opb, opa_stride, opb_stride, add_c1,
                                 key, out, gelt);
 }
 
+// packed half-done limbs (abc_ntt.hpp): only the sequence whose consumer is k_split4_main_fp reads them
+static inline int pack_half_done(const abc_hip_ctx *c, int nl) {
+  return (!c->sw.no_pack && !c->sw.no_split3 && !c->sw.no_split4 && nl >= 1 && nl <= 5) ? 1 : 0;
+}
 static inline bool all_fp(const abc_hip_ctx *c) {  // fp64 transforms: every key prime below 2^50
   bool fp = c->use_fp;
   for (int j = 0; j < c->K; j++) fp = fp && fp_ok(c->h_mods[j].bits);
@@ -1697,13 +1738,14 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
         // few ciphertexts in flight: the 139 KiB workgroups of the tensor kernel would leave most CUs idle for its whole
         // duration; the block-wise inverse tails + register cross pass of abc_kernels_gsplit.hip spread over the chip instead
         const bool lean = !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= 96;  // measured at nl = 4: +5 % at 16 pairs, even at 32, -5 % at 48
+        const int pack = pack_half_done(c, nl);
         if (lean)
-          gsplit_front14(st, c, cc, nl, 0, a + off * ctw, b + off * ctw, 0, (double *)s.coef, (double *)s.dec, 0u);
+          gsplit_front14(st, c, cc, nl, 0, a + off * ctw, b + off * ctw, 0, (double *)s.coef, (double *)s.dec, 0u, pack);
         else
           hipLaunchKernelGGL(k_split2_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
-                             b + off * ctw, (double *)s.dec, nl);
+                             b + off * ctw, (double *)s.dec, nl, pack);
         if (!c->sw.no_split3) {
-          launch_split3<0, false>(st, c, s, cc, nl, a + off * ctw, b + off * ctw, 0, 0, 0, c->d_relin, out + off * ctw, 0u);
+          launch_split3<0, false>(st, c, s, cc, nl, a + off * ctw, b + off * ctw, 0, 0, 0, c->d_relin, out + off * ctw, 0u, pack);
           ABC_HIP_CHECK(hipGetLastError());
           continue;
         }
@@ -1789,12 +1831,13 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     bool split = false;
     if constexpr (LB == 14) {
       split = all_fp(c) && !c->sw.no_split;
+      const int pack = (ckks && use2) ? pack_half_done(c, nl) : 0;
       if (split && ckks && use2 && !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= 96)
-        gsplit_front14(st, c, cc, nl, 1, tg, nullptr, target_stride, (double *)s.coef, (double *)s.dec, gelt);
+        gsplit_front14(st, c, cc, nl, 1, tg, nullptr, target_stride, (double *)s.coef, (double *)s.dec, gelt, pack);
       else if (split && ckks)
         hipLaunchKernelGGL((gelt ? k_fused_operand_pass0_fp<LB, true, true> : k_fused_operand_pass0_fp<LB, true, false>),
                            dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, 0,
-                           gelt, use2 ? 1 : 0);
+                           gelt, (use2 ? 1 : 0) | (pack ? 2 : 0));
       else if (split && cc * nl < c->sw.pass0_target_limit)
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl * (nl + 1))), dim3((1 << LB) / 16), 0, st,
                            c->dc, tg, target_stride, (double *)s.dec, nl, 1, 0u, useb ? 1 : 0);
@@ -1812,10 +1855,13 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
       if (split && ckks && !c->sw.no_split2 && nl <= 12) {
         const u64 *ad = addend ? addend + off * addend_stride : nullptr;
         if (!c->sw.no_split3) {
+          const int pack = pack_half_done(c, nl);
           if (gelt)
-            launch_split3<1, true>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, out + off * 2 * nl * N, gelt);
+            launch_split3<1, true>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, out + off * 2 * nl * N, gelt,
+                                   pack);
           else
-            launch_split3<1, false>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, out + off * 2 * nl * N, 0u);
+            launch_split3<1, false>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, out + off * 2 * nl * N, 0u,
+                                    pack);
           ABC_HIP_CHECK(hipGetLastError());
           continue;
         }

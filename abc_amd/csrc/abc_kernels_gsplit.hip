@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_gsplit_inv_tails(DevCtx c, const u64 *_
 
 // ---- G1b ----
 template <int LOGN>
-__global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__restrict__ hinv, double *__restrict__ part, int nl) {
+__global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__restrict__ hinv, double *__restrict__ part, int nl, int pack) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
   const int j = (int)((blockIdx.x >> 2) % (unsigned)nl);
@@ -143,8 +143,17 @@ __global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__
     for (int k = 0; k < NB; k++) y[k] = x[k];
     fwd_cross<LOGNB>(y, t, kk);
     double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * PS;
+    const int kind = (pack && I < nl) ? pack_kind(m.bits) : 0;  // packed half-done limbs (abc_ntt.hpp): N = 2^14, data primes only
+    if (kind == 0) {
 #pragma unroll
-    for (int k = 0; k < NB; k++) dst[(k << 10) + p] = y[k];
+      for (int k = 0; k < NB; k++) dst[(k << 10) + p] = y[k];
+    } else if (kind == 1) {
+#pragma unroll
+      for (int k = 0; k < NB; k++) pack_store<1>(dst, (size_t)1 << LOGN, (size_t)(k << 10) + p, fp_centre(y[k], kk.q, kk.qinv));
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; k++) pack_store<2>(dst, (size_t)1 << LOGN, (size_t)(k << 10) + p, fp_centre(y[k], kk.q, kk.qinv));
+    }
   }
 }
 
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(1024) void k_gsplit_main_deep(DevCtx c, const doubl
 // first step only (the half-done decomposition limbs): used by the N = 2^14 sequence for small batches
 template <int LOGN>
 static void launch_gsplit_front(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb,
-                                size_t opa_stride, double *hinv, double *part, u32 gelt) {
+                                size_t opa_stride, double *hinv, double *part, u32 gelt, int pack = 0) {
   constexpr int NB = 1 << (LOGN - 10);
   const dim3 g1((unsigned)(((cc + 3) / 4) * nl * NB)), g2((unsigned)(cc * nl * 4));
   const size_t lds = (size_t)(4 * lds_words(10)) * 8 + 1024 * 16;
@@ -531,11 +540,11 @@ static void launch_gsplit_front(hipStream_t st, abc_hip_ctx *c, size_t cc, int n
     hipLaunchKernelGGL((k_gsplit_inv_tails<LOGN, 1, true>), g1, dim3(256), lds, st, c->dc, opa, nullptr, opa_stride, hinv, nl, (int)cc, gelt);
   else
     hipLaunchKernelGGL((k_gsplit_inv_tails<LOGN, 1, false>), g1, dim3(256), lds, st, c->dc, opa, nullptr, opa_stride, hinv, nl, (int)cc, 0u);
-  hipLaunchKernelGGL((k_gsplit_cross<LOGN>), g2, dim3(256), 0, st, c->dc, hinv, part, nl);
+  hipLaunchKernelGGL((k_gsplit_cross<LOGN>), g2, dim3(256), 0, st, c->dc, hinv, part, nl, pack);
 }
 void gsplit_front14(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb, size_t opa_stride,
-                    double *hinv, double *part, u32 gelt) {
-  launch_gsplit_front<14>(st, c, cc, nl, mode, opa, opb, opa_stride, hinv, part, gelt);
+                    double *hinv, double *part, u32 gelt, int pack) {
+  launch_gsplit_front<14>(st, c, cc, nl, mode, opa, opb, opa_stride, hinv, part, gelt, pack);
 }
 
 template <int LOGN>

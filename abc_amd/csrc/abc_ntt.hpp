@@ -99,6 +99,44 @@ __device__ __forceinline__ u64 fp_to_lazy(double x, double q, double qinv) {
 }
 __host__ __device__ __forceinline__ bool fp_ok(u32 bits) { return bits <= 50; }
 
+// ---- packed half-done limbs (scratch traffic between the kernels of a split sequence) --------------------------------------
+// A half-done limb is written once and read once; as raw doubles it costs 8 bytes per coefficient each way although a centred
+// residue modulo a 40-bit prime is a signed 40-bit integer.  Packed form of a limb of N coefficients (inside the limb's
+// ordinary 8N-byte scratch slot): a plane of N low dwords, then a plane of N high bytes (kind 1: primes of at most 40 bits,
+// 5 bytes per coefficient) or N high half-words (kind 2: at most 48 bits, 6 bytes).  Planes, not interleaved records: a
+// wavefront's store instruction then still covers whole 32-byte sectors (64 consecutive dwords / bytes), and the consumer's
+// coefficient pair is one 8-byte plus one 2- or 4-byte load.  Kind 0: raw doubles (49- and 50-bit primes).
+// The value is the CENTRED representative c, |c| <= q/2, stored as a two's-complement integer: bits(c + 1.5 * 2^52) carries c's
+// low 48 bits in its mantissa; the reader rebuilds those bits with the sign-extended high part and subtracts the constant.
+__host__ __device__ __forceinline__ int pack_kind(u32 bits) { return bits <= 40 ? 1 : bits <= 48 ? 2 : 0; }
+constexpr double kPackMagic = 6755399441055744.0;  // 2^52 + 2^51
+template <int PK>
+__device__ __forceinline__ void pack_store(double *limb, size_t n, size_t idx, double centred) {
+  const u64 b = (u64)__double_as_longlong(centred + kPackMagic);
+  reinterpret_cast<u32 *>(limb)[idx] = (u32)b;
+  if (PK == 1) reinterpret_cast<unsigned char *>(limb)[4 * n + idx] = (unsigned char)(b >> 32);
+  else reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(limb) + 4 * n)[idx] = (unsigned short)(b >> 32);
+}
+// raw words of the coefficient pair (idx, idx + 1), idx even: .x = the two low dwords, .y = the two high parts
+template <int PK>
+__device__ __forceinline__ u64x2 pack_load_pair(const double *limb, size_t n, size_t idx) {
+  u64x2 r;
+  r.x = *reinterpret_cast<const u64 *>(reinterpret_cast<const u32 *>(limb) + idx);
+  if (PK == 1) r.y = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(limb) + 4 * n + idx);
+  else r.y = *reinterpret_cast<const u32 *>(reinterpret_cast<const unsigned char *>(limb) + 4 * n + 2 * idx);
+  return r;
+}
+template <int PK>
+__device__ __forceinline__ void pack_decode_pair(const u64x2 &r, double &v0, double &v1) {
+  const u32 h = (u32)r.y;
+  const int h0 = PK == 1 ? (int)(signed char)(h & 0xffu) : (int)(short)(h & 0xffffu);
+  const int h1 = PK == 1 ? (int)(signed char)((h >> 8) & 0xffu) : ((int)h >> 16);
+  const u64 b0 = ((u64)(u32)(0x43380000 + h0) << 32) | (u32)r.x;
+  const u64 b1 = ((u64)(u32)(0x43380000 + h1) << 32) | (u32)(r.x >> 32);
+  v0 = __longlong_as_double((long long)b0) - kPackMagic;
+  v1 = __longlong_as_double((long long)b1) - kPackMagic;
+}
+
 // ---- arithmetic policies of the register passes ---------------------------------------------------------
 // Integer (Harvey lazy) butterflies.
 // GUARD = false: no per-stage correction of X and the cheaper quotient estimate (mul_shoup_lazy4, product in

@@ -18,6 +18,8 @@ VARIANTS = {
     "fp64_unsplit": {"ABC_HIP_NO_SPLIT": "1"},
     "fp64_separate_kernels": {"ABC_HIP_NO_SPLIT": "1", "ABC_HIP_NO_TENSOR_DECOMP": "1"},
     "fp64_fat_front": {"ABC_HIP_NO_LEAN_FRONT": "1"},  # the 139 KiB tensor / operand kernel even for small batches
+    "fp64_unpacked": {"ABC_HIP_NO_PACK": "1"},  # half-done limbs as raw doubles (default: 5 / 6 bytes for primes <= 40 / 48 bits)
+    "fp64_unpacked_fat_front": {"ABC_HIP_NO_PACK": "1", "ABC_HIP_NO_LEAN_FRONT": "1"},
     "fp64_split_v1": {"ABC_HIP_NO_SPLIT2": "1"},  # round-1 kernels: four launches, LDS-atomic accumulators
     "fp64_split_v2": {"ABC_HIP_NO_SPLIT3": "1"},  # three launches, LDS-resident mod-down
     "fp64_split_serial_tail": {"ABC_HIP_TAILMAC_SERIAL": "1", "ABC_HIP_NO_SPLIT2": "1"},
@@ -93,7 +95,7 @@ def test_ckks14_paths_bit_exact(variant, oracle14, capi, monkeypatch):
     g.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
+@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "fp64_unpacked", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
 def test_ckks14_every_level_bit_exact(variant, oracle14, capi, monkeypatch):
     """multiply + relinearise and rotate at data levels 4, 3, 2 and 1 (the cooperative tail kernel runs nl wavefronts)"""
     o, primes, ins, want = oracle14
@@ -241,10 +243,51 @@ def test_ckks14_wide_prime_chains_every_level(chain, isplit, oracle_mod, capi, m
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# packed half-done limbs (abc_ntt.hpp): 5 bytes per coefficient modulo primes of at most 40 bits, 6 bytes up to 48 bits, raw
+# doubles above; every kind in one chain, every level, small batches (block-wise front) and large ones (139 KiB front kernel)
+# ---------------------------------------------------------------------------------------------------------------------
+PACK_CHAINS = {
+    "50_46x3_50": [50, 46, 46, 46, 50],        # kind 2 limbs between raw ones
+    "48_40_44_36_49": [48, 40, 44, 36, 49],    # kinds 2, 1, 2, 1 and a raw special prime
+    "41_40_48_49_50_47": [41, 40, 48, 49, 50, 47],  # five data limbs (the widest chain the packed sequence takes), kind-2 special prime
+}
+
+
+@pytest.mark.parametrize("front", ["lean", "fat"])
+@pytest.mark.parametrize("chain", list(PACK_CHAINS))
+def test_ckks14_packed_half_done_limbs(chain, front, oracle_mod, capi, monkeypatch):
+    if front == "fat":
+        monkeypatch.setenv("ABC_HIP_NO_LEAN_FRONT", "1")
+    n = 16384
+    primes = oracle_mod.create_primes(n, PACK_CHAINS[chain])
+    o = oracle_mod.Oracle(oracle_mod.CKKS, n, primes)
+    o.keygen(0xABC00077)
+    g = capi.Context(capi.CKKS, n, primes)
+    g.load_keys(sk=o.secret_key(), pk=o.public_key(), relin=o.relin_key(),
+                galois={e: o.galois_key(e) for e in o.galois_elts()})
+    rng = np.random.default_rng(77)
+    L = len(primes) - 1
+    x = np.stack([rng.integers(0, q, size=(2, n), dtype=np.uint64) for q in primes[:L]], axis=1)
+    y = _extreme_ct(primes, L, n, rng)
+    for level in range(L, 0, -1):
+        _same("%s mul_relin level %d" % (chain, level), g.mul_relin(x, y), o.mul_relin(x, y))
+        _same("%s mul_relin extreme level %d" % (chain, level), g.mul_relin(y, y), o.mul_relin(y, y))
+        _same("%s rotate level %d" % (chain, level), g.rotate(y, 3), o.rotate(y, 3))
+        _same("%s relinearize-style rotate (NAF) level %d" % (chain, level), g.rotate(x, 7), o.rotate(x, 7))
+        both = np.stack([x, y, x, y, y])
+        got = g.mul_relin(both, both[::-1].copy())
+        _same("%s batched mul_relin [1] level %d" % (chain, level), got[1], o.mul_relin(y, y))
+        _same("%s batched mul_relin [0] level %d" % (chain, level), got[0], o.mul_relin(x, y))
+        if level > 1:
+            x, y = o.mod_switch(x), o.mod_switch(y)
+    g.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # several chunks per lane: the hot call splits a batch into chunks that alternate over internal streams and reuse
 # per-lane scratch; every pair of a batch that spans chunk boundaries is checked, also with `out` aliasing `a`
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
+@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "fp64_unpacked", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
 def test_multi_chunk_batches_every_pair(variant, oracle14, capi, monkeypatch):
     import ctypes as C
     o, primes, ins, want = oracle14
