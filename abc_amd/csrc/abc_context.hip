@@ -35,6 +35,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_bsplit = env_on("ABC_HIP_NO_BSPLIT");
   s.no_mixed = env_on("ABC_HIP_NO_MIXED");
   s.no_pack = env_on("ABC_HIP_NO_PACK");
+  s.no_bmul = env_on("ABC_HIP_NO_BMUL");
   s.no_lean_front = env_on("ABC_HIP_NO_LEAN_FRONT");
   s.split4_special = env_on("ABC_HIP_SPLIT4_SPECIAL");
   s.no_tensor_decomp = env_on("ABC_HIP_NO_TENSOR_DECOMP");
@@ -950,6 +951,7 @@ int abc_hip_mul_relin(abc_hip_ctx *c, const uint64_t *a, const uint64_t *b, uint
     const int rc = ckks_mul_relin_fused(c, a, b, out, nl, count);
     if (rc >= 0) return rc;
   }
+  if (c->scheme == ABC_HIP_SCHEME_BFV && bmul_applies(c)) return bmul_split(c, a, b, out, count, true);
   // generic path: size-3 product in arena 1, then key switch
   const size_t bytes = count * 3 * nl * (size_t)c->n * 8;
   if (ensure_aux(c, 1, bytes ? bytes : 8)) return 1;

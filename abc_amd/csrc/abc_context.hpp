@@ -152,7 +152,7 @@ struct abc_hip_ctx {
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
   struct Switches {
-    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, no_bsplit = false, no_mixed = false, no_pack = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
+    bool no_fused = false, no_split = false, no_split2 = false, no_split3 = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, no_bsplit = false, no_mixed = false, no_pack = false, no_bmul = false, split4_special = false, no_tensor_decomp = false, no_tensor_intt = false;
     bool tailmac_serial = false, no_galois_fusion = false;
     size_t chunk = 0, few_limbs = 48, bfv_scratch_mb = 0, pass0_target_limit = 128;
     int lanes = 2;
@@ -256,6 +256,9 @@ int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u6
                size_t addend_stride, bool add_c1);
 int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
                   size_t addend_stride, int add_c1, u64 *out);
+// BFV multiply (+ relinearise) in split form, N = 2^14 (abc_kernels_bmul.hip)
+bool bmul_applies(const abc_hip_ctx *c);
+int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t count, bool relin);
 // integer twins of the split kernels (abc_kernels_isplit.hip)
 bool isplit_applies(const abc_hip_ctx *c, int nl);
 size_t isplit_scratch_words(const abc_hip_ctx *c, int nl);

@@ -467,6 +467,7 @@ static void launch_behz_floor(abc_hip_ctx *c, const u64 *dq, const u64 *dB, u64 
 int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t count) {
   if (c->scheme != 1) { set_error("bfv_multiply on a non-BFV context"); return 1; }
   if (!count) return 0;
+  if (bmul_applies(c)) return bmul_split(c, a, b, out3, count, false);  // N = 2^14, BFVDefault shape: abc_kernels_bmul.hip
   const size_t N = (size_t)c->n;
   const int L = c->L, nBsk = c->nBsk, nlm = L + nBsk;
   // per ciphertext pair (words): aq,bq 2*2L ; aB,bB 2*2nBsk ; dq 3L ; dB 3nBsk

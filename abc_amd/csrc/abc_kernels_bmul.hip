@@ -1,0 +1,328 @@
+// abc_kernels_bmul.hip -- BFV ciphertext x ciphertext multiply (BEHZ) in SPLIT form for N = 2^14: no LDS-resident limb, the
+// q -> Bsk extension fused into the forward cross pass, the fast floor + Shenoy-Kumaresan conversion fused into the inverse one,
+// and -- for multiply + relinearise -- the key switch's first register pass fused behind the floor.
+//
+// Reference call sites replaced: src/runtime/SealCiphertext.cpp:104-105,:122-123 (Evaluator::multiply + relinearize_inplace on
+// the reference's only scheme and default ring, include/ast_opt/runtime/SealCiphertextFactory.h:13).
+//
+// A 2^14-point transform = radix-16 cross pass over the 16 values at one position of every 1024-point block + 16 block tails
+// (abc_kernels_gsplit.hip).  The BEHZ steps between the transforms are element-wise over COEFFICIENTS and need every limb of a
+// coefficient; the cross passes are per LIMB and need 16 coefficients 1024 apart.  A workgroup therefore takes 32 positions x 16
+// blocks = 512 coefficients, all limbs, and turns them around in 68 KiB of LDS ([limb][block][position]):
+//   M1 k_bmul_front (ct, operand polynomial, position group): read the L q-residues of 512 coefficients, extend to Bsk
+//      (fastbconv_m_tilde + sm_mrq, the body of k_behz_extend_fp), park all L + nBsk limbs in LDS, then one thread per
+//      (limb, position) runs the forward cross pass -> half-done limbs hA.            32 limbs read, 68 written per pair (L = 8).
+//   M2 k_bmul_mid (ct, limb, block; four wavefronts = the four operand polynomials): forward block tails, dyadic tensor product
+//      in LDS, inverse block tails of the three product components -> hD.                                      68 read, 51 written.
+//   M3 k_bmul_back (ct, component, position group): inverse cross pass + N^-1 of all L + nBsk limbs -> LDS; per coefficient the
+//      fast floor and the conversion back to q (the body of k_behz_floor_fp); components 0, 1 -> the result; component 2 stays in
+//      LDS and every (digit, position) thread runs the key switch's forward cross pass modulo each key prime -> `part`, what
+//      k_fused_operand_pass0_fp<14, false, false> would have produced from a stored c2.                51 read, 16 + 72 written.
+// then k_gsplit_special<14, 8, true> / k_bsplit_tcoef / k_bsplit_finish_big (abc_kernels_gsplit.hip) with the result as addend.
+// 502 limb transfers per multiply + relinearise where the LDS-resident sequence (bfv_multiply's six kernels + the key switch's
+// four) moved ~730 (profiles/r02g_bfv16384_traffic_per_kernel.json: 96 MB per pair).  Same arithmetic as those kernels -- exact
+// fp64 residues, every prime (ciphertext and auxiliary) below 2^50 -- bit-identical results (tests/test_gpu_paths.py).
+#include <algorithm>
+
+#include "abc_context.hpp"
+
+namespace abc {
+
+namespace {
+
+constexpr int kPos = 32;  // positions per workgroup of M1 / M3: 256-byte runs in HBM, 512 coefficients in LDS
+
+__device__ __forceinline__ double m_mulmod(double x, double y, double q, double qinv) {  // |x|, |y| <= q -> |result| < q
+  const double h = x * y;
+  const double l = __builtin_fma(x, y, -h);
+  return __builtin_fma(-__builtin_rint(h * qinv), q, h) + l;
+}
+__device__ __forceinline__ double m_canon_d(double x, double q, double qinv) {  // any lazy value -> canonical [0, q) as a double
+  const double r = fp_centre(x, q, qinv);
+  return r < 0.0 ? r + q : r;
+}
+// constant rows fetched inside their own iteration (see abc_kernels_bfv.hip, row_after)
+template <class T>
+__device__ __forceinline__ const ABC_CONST_AS T *m_row_after(const ABC_CONST_AS T *p, u64 dep) {
+  asm volatile("" : "+s"(p) : "v"(dep));
+  return p;
+}
+// per-LANE modulus constants (a wavefront of the cross-pass phases works on two limbs)
+struct LaneMod {
+  FpK kk;
+  double inv_n_c, inv_n_cq;
+  FpTable t;
+};
+__device__ __forceinline__ LaneMod lane_mod(const DevCtx &c, int mid) {
+  const Mod *p = c.mods + mid;
+  LaneMod r;
+  r.kk.q = p->qd;
+  r.kk.qinv = p->qinv;
+  r.kk.red = p->bits >= 49;
+  r.inv_n_c = p->inv_n_c;
+  r.inv_n_cq = p->inv_n_cq;
+  r.t = fp_table(c, mid);
+  return r;
+}
+
+}  // namespace
+
+// ---- M1 ----
+template <int LT, int NBT>
+__global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b, double *__restrict__ hA) {
+  constexpr int L = LT, nBsk = NBT + 1, NLM = L + nBsk;
+  constexpr size_t N = (size_t)1 << 14;
+  extern __shared__ double dyn[];  // [NLM][16][kPos]
+  const ABC_CONST_AS DevConst &k = *(const ABC_CONST_AS DevConst *)c.cst;
+  const ABC_CONST_AS DevConstFp &f = *(const ABC_CONST_AS DevConstFp *)c.cstf;
+  const int pg = blockIdx.x & 31;
+  const int poly = (blockIdx.x >> 5) & 3;  // a0, a1, b0, b1
+  const size_t ct = blockIdx.x >> 7;
+  const int tid = threadIdx.x;
+  const size_t pw = (size_t)L * N;
+  const u64 *__restrict__ src = (poly < 2 ? a : b) + ct * 2 * pw + (size_t)(poly & 1) * pw;
+  {  // one coefficient per thread: (block kb, position p)
+    const int kb = tid >> 5, p = tid & 31;
+    const size_t x = ((size_t)kb << 10) + (size_t)(pg << 5) + p;
+    u64 raw[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) raw[i] = src[(size_t)i * N + x];
+    double tmp[L];
+    u32 mt = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const Mod m = mod_at(c, i);
+      const double v0 = fp_from_u64(raw[i]);
+      dyn[(i * 16 + kb) * kPos + p] = v0;
+      const double v = m_canon_d(fp_mul_lazy(v0, f.ext_q[i][0], f.ext_q[i][1], m.qd), m.qd, m.qinv);
+      tmp[i] = v;
+      mt += (u32)(u64)__double_as_longlong(v + 4503599627370496.0) * (u32)k.q_to_mtilde[i];  // mod 2^32 on the canonical residue
+    }
+    const u32 r32 = mt * (u32)k.neg_inv_q_mod_mtilde;
+    const double r = (double)(int)r32;  // centred representative of r mod m~
+    u64 dep = (u64)r32;
+#pragma unroll
+    for (int j = 0; j < nBsk; j++) {
+      const Mod m = mod_at(c, c.id_bsk + j);
+      const ABC_CONST_AS double *row = m_row_after(&f.q_to_bsk[j][0][0], dep);
+      double conv = fp_mul_lazy(r, f.q_mod_bsk[j][0], f.q_mod_bsk[j][1], m.qd);
+#pragma unroll
+      for (int i = 0; i < L; i++) conv += fp_mul_lazy(tmp[i], row[2 * i], row[2 * i + 1], m.qd);
+      const double v = m_canon_d(fp_mul_lazy(conv, f.inv_mtilde_mod_bsk[j][0], f.inv_mtilde_mod_bsk[j][1], m.qd), m.qd, m.qinv);
+      dep = (u64)__double_as_longlong(v);
+      dyn[((L + j) * 16 + kb) * kPos + p] = v;
+    }
+  }
+  __syncthreads();
+  const int hi0[1] = {0};
+  for (int job = tid; job < NLM * kPos; job += 512) {  // one (limb, position) column per thread; the last limb is a second round
+    const int l = job >> 5, p = job & 31;
+    const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
+    double x[16];
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) x[kb] = dyn[(l * 16 + kb) * kPos + p];
+    fwd_pass<FpArith, 14, 0, 4>(x, hi0, lm.t, lm.kk, 0, 0);
+    double *__restrict__ dst = hA + ((ct * 4 + poly) * NLM + l) * N + (size_t)(pg << 5) + p;
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) dst[(size_t)kb << 10] = x[kb];
+  }
+}
+
+// ---- M2 ----
+__global__ __launch_bounds__(256) void k_bmul_mid(DevCtx c, const double *__restrict__ hA, double *__restrict__ hD, int nlm, int L) {
+  constexpr int LOGNB = 4;
+  constexpr size_t N = (size_t)1 << 14;
+  __shared__ double lds[4 * lds_words(10)];
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x & 15;
+  const int l = (int)((blockIdx.x >> LOGNB) % (unsigned)nlm);
+  const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)nlm);
+  const int mid = l < L ? l : c.id_bsk + (l - L);
+  const Mod m = mod_at(c, mid);
+  const FpTable t = fp_table(c, mid);
+  const double q = m.qd, qinv = m.qinv;
+  const size_t base = (size_t)blk << 10;
+  double *buf = lds + W * lds_words(10);
+  {  // wavefront W: forward tail of operand polynomial W (a0, a1, b0, b1), centred result parked in LDS
+    const double *__restrict__ src = hA + ((ct * 4 + W) * nlm + l) * N + base;
+    ntt_fwd_block_a<10, FpArith>(
+        buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = fp_centre(v, q, qinv); }, t,
+        m, LOGNB, blk, lane);
+  }
+  __syncthreads();
+  for (int e = 2 * (int)threadIdx.x; e < 1024; e += 512) {  // dyadic tensor product, in place (a thread rewrites only what it read)
+    double *p0 = lds + lds_pad(e), *p1 = p0 + lds_words(10), *p2 = p1 + lds_words(10), *p3 = p2 + lds_words(10);
+    const f64x2 a0 = *reinterpret_cast<const f64x2 *>(p0), a1 = *reinterpret_cast<const f64x2 *>(p1);
+    const f64x2 b0 = *reinterpret_cast<const f64x2 *>(p2), b1 = *reinterpret_cast<const f64x2 *>(p3);
+    f64x2 d;
+    d.x = m_mulmod(a0.x, b0.x, q, qinv);
+    d.y = m_mulmod(a0.y, b0.y, q, qinv);
+    *reinterpret_cast<f64x2 *>(p0) = d;
+    d.x = fp_centre(m_mulmod(a0.x, b1.x, q, qinv) + m_mulmod(a1.x, b0.x, q, qinv), q, qinv);
+    d.y = fp_centre(m_mulmod(a0.y, b1.y, q, qinv) + m_mulmod(a1.y, b0.y, q, qinv), q, qinv);
+    *reinterpret_cast<f64x2 *>(p1) = d;
+    d.x = m_mulmod(a1.x, b1.x, q, qinv);
+    d.y = m_mulmod(a1.y, b1.y, q, qinv);
+    *reinterpret_cast<f64x2 *>(p2) = d;
+  }
+  __syncthreads();
+  if (W < 3) {  // inverse tail of product component W; N^-1 belongs to the cross pass (M3)
+    double *__restrict__ dst = hD + ((ct * 3 + W) * nlm + l) * N + base;
+    ntt_inv_block_a<10, FpArith>(
+        buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, LOGNB, blk, lane);
+  }
+}
+
+// ---- M3 ----
+// want3 = 1: plain multiply, all three components to out [ct][3][L][N], no key-switch pass
+template <int LT, int NBT>
+__global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__restrict__ hD, u64 *__restrict__ out, double *__restrict__ part,
+                                                      int want3) {
+  constexpr int L = LT, nB = NBT, nBsk = NBT + 1, NLM = L + nBsk;
+  constexpr size_t N = (size_t)1 << 14;
+  extern __shared__ double dyn[];  // [NLM][16][kPos]
+  const ABC_CONST_AS DevConstFp &f = *(const ABC_CONST_AS DevConstFp *)c.cstf;
+  const int pg = blockIdx.x & 31;
+  const int comp = (int)((blockIdx.x >> 5) % 3u);
+  const size_t ct = (size_t)((blockIdx.x >> 5) / 3u);
+  const int tid = threadIdx.x;
+  const int hi0[1] = {0};
+  for (int job = tid; job < NLM * kPos; job += 512) {  // inverse cross pass + N^-1 of one (limb, position) column
+    const int l = job >> 5, p = job & 31;
+    const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
+    const double *__restrict__ src = hD + ((ct * 3 + comp) * NLM + l) * N + (size_t)(pg << 5) + p;
+    double x[16];
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) x[kb] = src[(size_t)kb << 10];
+    FpArith::centre16(x, lm.kk);
+    inv_pass<FpArith, 14, 0, 4>(x, hi0, lm.t, lm.kk, 0, 0);
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) dyn[(l * 16 + kb) * kPos + p] = fp_mul_lazy(x[kb], lm.inv_n_c, lm.inv_n_cq, lm.kk.q);
+  }
+  __syncthreads();
+  {  // BEHZ steps (6)-(8) on one coefficient per thread (k_behz_floor_fp): scale by t, fast floor by q, Shenoy-Kumaresan back to q
+    const int kb = tid >> 5, p = tid & 31;
+    const size_t x = ((size_t)kb << 10) + (size_t)(pg << 5) + p;
+    const Mod msk = mod_at(c, c.id_bsk + nB);
+    double tq[L], fl[nBsk];
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const Mod m = mod_at(c, i);
+      tq[i] = m_canon_d(fp_mul_lazy(dyn[(i * 16 + kb) * kPos + p], f.flr_q[i][0], f.flr_q[i][1], m.qd), m.qd, m.qinv);
+    }
+    u64 dep = (u64)__double_as_longlong(tq[L - 1]);
+#pragma unroll
+    for (int j = 0; j < nBsk; j++) {
+      const Mod m = mod_at(c, c.id_bsk + j);
+      const ABC_CONST_AS double *row = m_row_after(&f.q_to_bsk[j][0][0], dep);
+      double conv = 0.0;
+#pragma unroll
+      for (int i = 0; i < L; i++) conv += fp_mul_lazy(tq[i], row[2 * i], row[2 * i + 1], m.qd);
+      const double xb = fp_mul_lazy(dyn[((L + j) * 16 + kb) * kPos + p], f.tinvq_bsk[j][0], f.tinvq_bsk[j][1], m.qd);
+      fl[j] = xb - fp_mul_lazy(conv, f.inv_q_mod_bsk[j][0], f.inv_q_mod_bsk[j][1], m.qd);
+      dep = (u64)__double_as_longlong(fl[j]);
+    }
+    double tb[nB];
+#pragma unroll
+    for (int b2 = 0; b2 < nB; b2++) {
+      const Mod m = mod_at(c, c.id_bsk + b2);
+      tb[b2] = m_canon_d(fp_mul_lazy(fl[b2], f.inv_punct_B[b2][0], f.inv_punct_B[b2][1], m.qd), m.qd, m.qinv);
+    }
+    double mconv = -fl[nB];
+#pragma unroll
+    for (int b2 = 0; b2 < nB; b2++) mconv += fp_mul_lazy(tb[b2], f.B_to_msk[b2][0], f.B_to_msk[b2][1], msk.qd);
+    double alpha = m_canon_d(fp_mul_lazy(mconv, f.inv_B_mod_msk[0], f.inv_B_mod_msk[1], msk.qd), msk.qd, msk.qinv);
+    if (alpha > (double)(msk.q >> 1)) alpha -= msk.qd;
+    dep = (u64)__double_as_longlong(alpha);
+    const bool to_out = want3 || comp < 2;  // workgroup-uniform
+    u64 *__restrict__ o = out + (ct * (want3 ? 3 : 2) + comp) * (size_t)L * N + x;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const Mod m = mod_at(c, i);
+      const ABC_CONST_AS double *row = m_row_after(&f.B_to_q[i][0][0], dep);
+      double v = -fp_mul_lazy(alpha, f.B_mod_q[i][0], f.B_mod_q[i][1], m.qd);
+#pragma unroll
+      for (int b2 = 0; b2 < nB; b2++) v += fp_mul_lazy(tb[b2], row[2 * b2], row[2 * b2 + 1], m.qd);
+      if (to_out) {
+        const u64 w = fp_to_canon(v, m.qd, m.qinv);
+        dep = w;
+        o[(size_t)i * N] = w;
+      } else {  // c2: canonical [0, q_i) as a double, the value the key switch's decomposition reduces modulo the other primes
+        const double w = m_canon_d(v, m.qd, m.qinv);
+        dep = (u64)__double_as_longlong(w);
+        dyn[(i * 16 + kb) * kPos + p] = w;
+      }
+    }
+    if (to_out) return;
+  }
+  __syncthreads();
+  // key switch, first step: digit J of c2 at this position group, forward cross pass modulo every key prime I (two halves of the
+  // key primes on two sets of wavefronts) -> part[ct][I][J], the layout k_gsplit_special<14, L, true> reads
+  const size_t PS = (size_t)c.ps;
+  for (int job = tid; job < L * kPos * 2; job += 512) {
+    const int p = job & 31, J = (job >> 5) % L;
+    const int half = __builtin_amdgcn_readfirstlane((job >> 5) / L);  // wave-uniform: a wavefront covers two J of one half (L even)
+    const int I0 = half ? (L + 2) / 2 : 0, I1 = half ? L + 1 : (L + 2) / 2;
+    double x[16];
+#pragma unroll
+    for (int kb = 0; kb < 16; kb++) x[kb] = dyn[(J * 16 + kb) * kPos + p];
+    for (int I = I0; I < I1; I++) {
+      const int ki = (I == L) ? c.K - 1 : I;
+      const Mod m = mod_at(c, ki);
+      const FpTable t = fp_table(c, ki);
+      const FpK kk = FpArith::consts(m);
+      double y[16];
+#pragma unroll
+      for (int kb = 0; kb < 16; kb++) y[kb] = x[kb];
+      fwd_pass<FpArith, 14, 0, 4>(y, hi0, t, kk, 0, 0);
+      double *__restrict__ dst = part + ((ct * (L + 1) + I) * L + J) * PS + (size_t)(pg << 5) + p;
+#pragma unroll
+      for (int kb = 0; kb < 16; kb++) dst[(size_t)kb << 10] = y[kb];
+    }
+  }
+}
+
+// ---- host side ----
+bool bmul_applies(const abc_hip_ctx *c) {
+  return c->scheme == 1 && c->logn == 14 && c->use_fp && c->behz_fp && !c->sw.no_bmul && c->L == 8 && c->nB == 8 && c->K == c->L + 1 &&
+         bsplit_applies(c, c->L);
+}
+
+// scratch per ciphertext pair (words): X = max(hA, part) | Y = max(hD, half + tco)
+static size_t bmul_scratch_words(const abc_hip_ctx *c) {
+  const size_t N = (size_t)c->n, PS = (size_t)c->dc.ps;
+  const int L = c->L, nlm = c->L + c->nBsk;
+  const size_t X = std::max((size_t)4 * nlm * N, (size_t)L * (L + 1) * PS);
+  const size_t Y = std::max((size_t)3 * nlm * N, (size_t)(2 * (L + 1) + 2) * PS);
+  return X + Y;
+}
+
+// relin = true: out [count][2][L][N] = relinearised product; false: out [count][3][L][N] = the size-3 product
+int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t count, bool relin) {
+  if (!count) return 0;
+  const size_t N = (size_t)c->n, PS = (size_t)c->dc.ps;
+  const int L = c->L, nlm = c->L + c->nBsk;
+  const size_t per_ct = bmul_scratch_words(c);
+  size_t chunk = c->sw.chunk ? c->sw.chunk : 64;
+  if (c->sw.bfv_scratch_mb) chunk = std::max<size_t>(1, (c->sw.bfv_scratch_mb << 20) / 8 / per_ct);
+  if (chunk > count) chunk = count;
+  if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
+  const size_t Xw = std::max((size_t)4 * nlm * N, (size_t)L * (L + 1) * PS);
+  const size_t lds = (size_t)nlm * 16 * kPos * 8;
+  hipStream_t st = c->stream;
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t cc = (count - off < chunk) ? count - off : chunk;
+    double *X = (double *)c->ws, *Y = X + cc * Xw;
+    const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
+    u64 *po = out + off * (relin ? 2 : 3) * L * N;
+    hipLaunchKernelGGL((k_bmul_front<8, 8>), dim3((unsigned)(cc * 4 * 32)), dim3(512), lds, st, c->dc, pa, pb, X);
+    hipLaunchKernelGGL(k_bmul_mid, dim3((unsigned)(cc * nlm * 16)), dim3(256), 0, st, c->dc, (const double *)X, Y, nlm, L);
+    hipLaunchKernelGGL((k_bmul_back<8, 8>), dim3((unsigned)(cc * 3 * 32)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, relin ? 0 : 1);
+    ABC_HIP_CHECK(hipGetLastError());
+    if (relin && bsplit_back14(c, st, cc, L, (const double *)X, Y, c->d_relin, po, 2 * (size_t)L * N, 1, po)) return 1;
+  }
+  return 0;
+}
+
+}  // namespace abc
