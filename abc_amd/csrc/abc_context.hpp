@@ -256,6 +256,30 @@ int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u6
                size_t addend_stride, bool add_c1);
 int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
                   size_t addend_stride, int add_c1, u64 *out);
+// internal lanes (streams forked off the context's stream): chunks of one call alternate over them (abc_kernels_fused.hip)
+int fork_lanes(abc_hip_ctx *c, int lanes);
+int join_lanes(abc_hip_ctx *c, int lanes);
+// fork on construction (fork()), join on every way out: an early `return 1` between the two would otherwise leave work on
+// the lanes that the context's stream -- and with it every later use or release of the buffers involved -- never waits for
+struct LaneScope {
+  abc_hip_ctx *c;
+  int lanes;
+  bool forked = false;
+  LaneScope(abc_hip_ctx *c_, int lanes_) : c(c_), lanes(lanes_) {}
+  int fork() {
+    if (fork_lanes(c, lanes)) return 1;
+    forked = true;
+    return 0;
+  }
+  int join() {
+    forked = false;
+    return join_lanes(c, lanes);
+  }
+  ~LaneScope() {
+    if (forked) (void)join_lanes(c, lanes);
+  }
+};
+
 // BFV multiply (+ relinearise) in split form, N = 2^14 (abc_kernels_bmul.hip)
 bool bmul_applies(const abc_hip_ctx *c);
 int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t count, bool relin);

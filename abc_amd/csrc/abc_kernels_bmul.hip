@@ -304,16 +304,23 @@ int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t coun
   const size_t N = (size_t)c->n, PS = (size_t)c->dc.ps;
   const int L = c->L, nlm = c->L + c->nBsk;
   const size_t per_ct = bmul_scratch_words(c);
+  // chunks alternate over the context's internal lanes, as in the CKKS hot call (plan_chunks, abc_kernels_fused.hip)
+  int lanes = c->sw.lanes;
+  if (count <= 8 || lanes < 1) lanes = 1;
   size_t chunk = c->sw.chunk ? c->sw.chunk : 64;
-  if (c->sw.bfv_scratch_mb) chunk = std::max<size_t>(1, (c->sw.bfv_scratch_mb << 20) / 8 / per_ct);
-  if (chunk > count) chunk = count;
-  if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
+  if (c->sw.bfv_scratch_mb) chunk = std::max<size_t>(1, (c->sw.bfv_scratch_mb << 20) / 8 / per_ct / (size_t)lanes);
+  if (chunk * lanes > count) chunk = (count + lanes - 1) / lanes;
+  if (ensure_workspace(c, (size_t)lanes * chunk * per_ct * 8)) return 1;
   const size_t Xw = std::max((size_t)4 * nlm * N, (size_t)L * (L + 1) * PS);
   const size_t lds = (size_t)nlm * 16 * kPos * 8;
-  hipStream_t st = c->stream;
-  for (size_t off = 0; off < count; off += chunk) {
+  LaneScope scope(c, lanes);
+  if (scope.fork()) return 1;
+  int turn = 0;
+  for (size_t off = 0; off < count; off += chunk, turn++) {
     const size_t cc = (count - off < chunk) ? count - off : chunk;
-    double *X = (double *)c->ws, *Y = X + cc * Xw;
+    const int ln = (lanes > 1) ? turn % lanes : 0;
+    hipStream_t st = (lanes > 1) ? c->lane[ln] : c->stream;
+    double *X = (double *)c->ws + (size_t)ln * chunk * per_ct, *Y = X + cc * Xw;
     const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
     u64 *po = out + off * (relin ? 2 : 3) * L * N;
     hipLaunchKernelGGL((k_bmul_front<8, 8>), dim3((unsigned)(cc * 4 * 32)), dim3(512), lds, st, c->dc, pa, pb, X);
@@ -322,7 +329,7 @@ int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t coun
     ABC_HIP_CHECK(hipGetLastError());
     if (relin && bsplit_back14(c, st, cc, L, (const double *)X, Y, c->d_relin, po, 2 * (size_t)L * N, 1, po)) return 1;
   }
-  return 0;
+  return scope.join();
 }
 
 }  // namespace abc

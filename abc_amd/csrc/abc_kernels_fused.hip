@@ -1623,7 +1623,7 @@ __global__ void k_lane_delay(unsigned ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 
-static int fork_lanes(abc_hip_ctx *c, int lanes) {
+int fork_lanes(abc_hip_ctx *c, int lanes) {
   if (lanes < 2) return 0;
   ABC_HIP_CHECK(hipEventRecord(c->lane_fork, c->stream));
   for (int l = 0; l < lanes; l++) ABC_HIP_CHECK(hipStreamWaitEvent(c->lane[l], c->lane_fork, 0));
@@ -1632,7 +1632,7 @@ static int fork_lanes(abc_hip_ctx *c, int lanes) {
     for (int l = 1; l < lanes; l++) hipLaunchKernelGGL(k_lane_delay, dim3(1), dim3(64), 0, c->lane[l], us * 100u * l);
   return 0;
 }
-static int join_lanes(abc_hip_ctx *c, int lanes) {
+int join_lanes(abc_hip_ctx *c, int lanes) {
   if (lanes < 2) return 0;
   for (int l = 0; l < lanes; l++) {
     ABC_HIP_CHECK(hipEventRecord(c->lane_join[l], c->lane[l]));
@@ -1640,27 +1640,6 @@ static int join_lanes(abc_hip_ctx *c, int lanes) {
   }
   return 0;
 }
-
-// fork on construction (fork()), join on every way out: an early `return 1` between the two would otherwise leave work on
-// the lanes that the context's stream -- and with it every later use or release of the buffers involved -- never waits for
-struct LaneScope {
-  abc_hip_ctx *c;
-  int lanes;
-  bool forked = false;
-  LaneScope(abc_hip_ctx *c_, int lanes_) : c(c_), lanes(lanes_) {}
-  int fork() {
-    if (fork_lanes(c, lanes)) return 1;
-    forked = true;
-    return 0;
-  }
-  int join() {
-    forked = false;
-    return join_lanes(c, lanes);
-  }
-  ~LaneScope() {
-    if (forked) (void)join_lanes(c, lanes);
-  }
-};
 
 static int run_isplit(abc_hip_ctx *c, int mode, const u64 *opa, const u64 *opb, size_t opa_stride, size_t opb_stride, bool add_c1,
                       const u64 *key, u64 *out, int nl, size_t count, u32 gelt) {
