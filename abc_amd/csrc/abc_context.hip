@@ -11,6 +11,8 @@
 #include <mutex>
 
 #include "../../include/abc_hip.h"
+#include <dlfcn.h>
+
 #include "abc_context.hpp"
 #include "abc_host_math.hpp"
 
@@ -503,7 +505,42 @@ static int relinearize(abc_hip_ctx *c, const u64 *ct3, u64 *out2, int nl, size_t
 
 using namespace abc;
 
+// roctx range around every C-ABI operation (rocprofv3 --marker-trace then shows the op boundaries above the kernel rows; the
+// reference's only instrumentation is four wall-clock phase timers, examples/main.cpp:41).  The marker library is bound with
+// dlopen on first use -- libabc_hip.so carries no link-time dependency on a profiler -- and ABC_HIP_NO_ROCTX=1 skips it.
+namespace abc {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (env_on("ABC_HIP_NO_ROCTX")) return;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+        push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+      }
+    }
+  }
+};
+static const Roctx &roctx() {
+  static const Roctx r;
+  return r;
+}
+struct OpRange {
+  bool on;
+  explicit OpRange(const char *name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~OpRange() {
+    if (on) roctx().pop();
+  }
+};
+}  // namespace abc
+
 #define CTX_GUARD(c)                                   \
+  abc::OpRange abc_op_range_(__func__);                \
   do {                                                 \
     if (!(c)) { set_error("null context"); return 1; } \
     if (hipSetDevice((c)->device) != hipSuccess) { set_error("hipSetDevice failed"); return 1; } \
@@ -723,6 +760,32 @@ int abc_hip_sync(abc_hip_ctx *c) {
 // (hipMallocAsync / hipFreeAsync were tried first and returned wrong results on some boxes of this pool when two
 // contexts alternated -- analysis in DESIGN.md section 4b; ABC_HIP_SYNC_ALLOC=1 turns the cache off.)
 static void *const kCapturing = (void *)(uintptr_t)1;
+// pin bookkeeping (callers hold alloc_mu)
+static void pin_add(abc_hip_ctx *c, void *p, void *owner) {
+  auto &v = c->pin[p];
+  for (void *o : v)
+    if (o == owner) return;
+  v.push_back(owner);
+}
+// drop `owner` from block p; a block nobody owns any more and that its user has already freed returns to the cache
+static void pin_drop(abc_hip_ctx *c, void *p, void *owner) {
+  auto it = c->pin.find(p);
+  if (it == c->pin.end()) return;
+  auto &v = it->second;
+  for (size_t i = 0; i < v.size(); i++)
+    if (v[i] == owner) {
+      v[i] = v.back();
+      v.pop_back();
+      break;
+    }
+  if (!v.empty()) return;
+  c->pin.erase(it);
+  if (c->parked.erase(p)) {
+    const size_t sz = c->block_size[p];
+    c->free_blocks[sz].push_back(p);
+    c->cached_bytes += sz;
+  }
+}
 
 int abc_hip_malloc(abc_hip_ctx *c, void **d_ptr, size_t bytes) {
   CTX_GUARD(c);
@@ -745,7 +808,7 @@ int abc_hip_malloc(abc_hip_ctx *c, void **d_ptr, size_t bytes) {
       it->second.pop_back();
       c->cached_bytes -= bytes;
       if (c->capture_active) {
-        c->pin[*d_ptr] = kCapturing;
+        pin_add(c, *d_ptr, kCapturing);
         c->cap_born[*d_ptr] = true;
       }
       return 0;
@@ -775,7 +838,7 @@ int abc_hip_free(abc_hip_ctx *c, void *d_ptr) {
           if (c->cap_born.count(d_ptr)) {  // an intermediate of the circuit being recorded
             c->cap_free[it->second].push_back(d_ptr);
           } else {  // existed before: the graph reads it as an input on every replay -- pinned, never reused
-            c->pin[d_ptr] = kCapturing;
+            pin_add(c, d_ptr, kCapturing);
             c->parked[d_ptr] = true;
           }
           return 0;
@@ -1055,7 +1118,8 @@ int abc_hip_graph_begin(abc_hip_ctx *c) {
   c->capture_active = true;
   return 0;
 }
-// hand every block the finished (or abandoned) capture touched to `owner`; owner = nullptr releases them
+// hand every block the finished capture may have baked into the graph to `owner`; owner = nullptr (abandoned capture) releases
+// what the capture had pinned
 static void settle_capture(abc_hip_ctx *c, void *owner) {
   std::lock_guard<std::mutex> lock(c->alloc_mu);
   c->capture_active = false;
@@ -1065,19 +1129,20 @@ static void settle_capture(abc_hip_ctx *c, void *owner) {
   c->cap_born.clear();
   std::vector<void *> mine;
   for (auto &kv : c->pin)
-    if (kv.second == kCapturing) mine.push_back(kv.first);
+    for (void *o : kv.second)
+      if (o == kCapturing) mine.push_back(kv.first);
   for (void *p : mine) {
-    if (owner) {
-      c->pin[p] = owner;
-    } else {
-      c->pin.erase(p);
-      if (c->parked.erase(p)) {
-        const size_t sz = c->block_size[p];
-        c->free_blocks[sz].push_back(p);
-        c->cached_bytes += sz;
-      }
-    }
+    if (owner) pin_add(c, p, owner);
+    pin_drop(c, p, kCapturing);
   }
+  if (!owner) return;
+  // every block still out with the caller: the recorded kernels may read it (an operand that existed before the capture and is
+  // freed only later never passed through abc_hip_malloc / abc_hip_free while capture_active was set)
+  std::unordered_map<void *, bool> cached;
+  for (auto &kv : c->free_blocks)
+    for (void *p : kv.second) cached[p] = true;
+  for (auto &kv : c->block_size)
+    if (!cached.count(kv.first)) pin_add(c, kv.first, owner);
 }
 int abc_hip_graph_end(abc_hip_ctx *c, void **out) {
   CTX_GUARD(c);
@@ -1110,15 +1175,9 @@ int abc_hip_graph_destroy(abc_hip_ctx *c, void *exec) {
   std::lock_guard<std::mutex> lock(c->alloc_mu);
   std::vector<void *> mine;
   for (auto &kv : c->pin)
-    if (kv.second == exec) mine.push_back(kv.first);
-  for (void *p : mine) {  // unpin; what the caller had already freed goes back to the cache now
-    c->pin.erase(p);
-    if (c->parked.erase(p)) {
-      const size_t sz = c->block_size[p];
-      c->free_blocks[sz].push_back(p);
-      c->cached_bytes += sz;
-    }
-  }
+    for (void *o : kv.second)
+      if (o == exec) mine.push_back(kv.first);
+  for (void *p : mine) pin_drop(c, p, exec);  // unpin; what the caller had already freed goes back to the cache now
   return 0;
 }
 

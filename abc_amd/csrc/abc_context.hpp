@@ -138,12 +138,15 @@ struct abc_hip_ctx {
   size_t cached_bytes = 0, cache_cap = (size_t)8 << 30;
   std::unordered_map<size_t, std::vector<void *>> free_blocks;  // size -> cached blocks
   std::unordered_map<void *, size_t> block_size;                 // every live block handed out by abc_hip_malloc
-  // Blocks a recorded circuit (abc_hip_graph_*) has baked into its kernel arguments are PINNED to it: while the graph exists
-  // they never go back to the free list, whoever frees them.  pin: block -> owning graph (kCapturing until graph_end names it);
-  // parked: pinned blocks the caller has already freed (released to the cache when the graph is destroyed);
-  // cap_free: blocks allocated AND freed during the running capture, reusable inside it (stream order inside the graph).
+  // Blocks a recorded circuit (abc_hip_graph_*) may have baked into its kernel arguments are PINNED to it: while the graph exists
+  // they never go back to the free list, whoever frees them.  Pinned = every block this context had handed out and not yet got
+  // back when abc_hip_graph_end ran (a superset of what the sequence read: operands that existed before the capture -- cached
+  // plaintexts, inputs -- are covered without tracing every pointer argument) plus every block the capture itself took from the
+  // cache.  pin: block -> graphs that own it (kCapturing stands for the capture in progress); parked: pinned blocks the caller
+  // has already freed (released to the cache when their last graph is destroyed); cap_free: blocks allocated AND freed during the
+  // running capture, reusable inside it (stream order inside the graph).
   bool capture_active = false;
-  std::unordered_map<void *, void *> pin;
+  std::unordered_map<void *, std::vector<void *>> pin;
   std::unordered_map<void *, bool> parked;
   std::unordered_map<size_t, std::vector<void *>> cap_free;
   std::unordered_map<void *, bool> cap_born;  // allocated during the running capture

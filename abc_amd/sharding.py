@@ -19,18 +19,26 @@ def shard_range(total, rank, world):
 
 def gather_results(local, total, dst=0):
     """Gather per-rank result tensors [n_local, ...] into [total, ...] on rank `dst` (None elsewhere).
-    Ranks may hold different n_local (ragged tail); shards are padded to the largest block for the collective."""
+    Ranks may hold different n_local (ragged tail).  Rank `dst` allocates the result once and receives every other rank's block
+    straight into its slice (point-to-point send / recv: xGMI links into one GPU under RCCL, sockets under gloo) -- no padded
+    staging buffers and no concatenation, so the transient footprint is the result itself (an 8-way gather of 1 GiB blocks
+    through `dist.gather` + `cat` would hold 16 GiB)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     sizes = [shard_range(total, r, world) for r in range(world)]
-    biggest = max(b - a for a, b in sizes)
-    padded = local
-    if local.shape[0] < biggest:
-        pad = torch.zeros((biggest - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        padded = torch.cat([local, pad], dim=0)
-    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded.contiguous(), bufs, dst=dst)
+    lo, hi = sizes[rank]
+    if local.shape[0] != hi - lo:
+        raise ValueError("rank %d holds %d units, its block of %d is %d" % (rank, local.shape[0], total, hi - lo))
+    local = local.contiguous()
     if rank != dst:
+        if hi > lo:
+            dist.send(local, dst)
         return None
-    return torch.cat([bufs[r][: sizes[r][1] - sizes[r][0]] for r in range(world)], dim=0)
+    out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    out[lo:hi] = local
+    for r in range(world):
+        a, b = sizes[r]
+        if r != dst and b > a:
+            dist.recv(out[a:b], r)  # a leading-dimension slice of a contiguous tensor is contiguous
+    return out

@@ -36,6 +36,7 @@ BITS_60 = [60, 40, 40, 40, 60]  # a SEAL-typical chain: 60-bit primes take the i
 L = 4
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 ALGO_BYTES = 8 * N * (6 * L + 2 * L * (L + 1))  # = 8 388 608 B per mul+relin
+ALGO_BYTES_KEY_RESIDENT = 8 * N * 6 * L  # = 3 145 728 B: the same with the relin key counted as cache-resident across the batch
 
 
 def parse(argv=None):
@@ -58,51 +59,9 @@ def parse(argv=None):
 # ---------------------------------------------------------------------------------------------------------------------
 # launcher: N fresh rank processes, started before anything in this process initialises the GPU
 # ---------------------------------------------------------------------------------------------------------------------
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def launch_ranks(args):
-    port = _free_port()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else None))
-    # relay rank 0's output; if any rank dies, stop the others (they would wait in the rendezvous for ever)
-    out0 = []
-    rc = 0
-    import threading
-
-    def pump():
-        for raw in procs[0].stdout:
-            out0.append(raw.decode())
-
-    th = threading.Thread(target=pump, daemon=True)
-    th.start()
-    live = set(range(args.gpus))
-    while live:
-        for r in list(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = code
-                for o in live:
-                    procs[o].terminate()  # exactly the PIDs started above
-        time.sleep(0.05)
-    th.join(timeout=5)
-    sys.stdout.write("".join(out0))
-    sys.stdout.flush()
-    return rc
+    from abc_amd.launcher import launch_ranks as _launch  # imports neither torch nor HIP
+    return _launch(__file__, sys.argv[1:], args.gpus)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -149,18 +108,20 @@ def cpu_baseline(primes, seconds):
 def measured_traffic(batch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in
     separate runs and corrected as MI355X_MICROARCH.md prescribes; newest profiles/r*_pmc_traffic.json,
-    produced by tools/pmc_traffic.sh), scaled to this batch.  bench.py cannot collect PMC counters itself; None
-    if the profile is absent."""
+    produced by tools/pmc_traffic.sh), scaled to this batch.  bench.py cannot collect PMC counters itself: the figure is
+    NOT measured in this run, and `source` says which profile (and which batch) it was scaled from.  (None, None) if absent."""
     try:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
             with open(path) as f:
                 prof = json.load(f)
             if "hbm_bytes_per_mul_relin" in prof:  # profiles of other operations carry other keys
-                return prof["hbm_bytes_per_mul_relin"] * batch
-        return None
+                src = "%s: %.2f MB per mul+relin measured at batch %s under rocprofv3 --pmc, scaled by this run's batch" % (
+                    os.path.relpath(path, ROOT), prof["hbm_bytes_per_mul_relin"] / 1e6, prof.get("hot_call", {}).get("batch", "?"))
+                return prof["hbm_bytes_per_mul_relin"] * batch, src
+        return None, None
     except Exception:
-        return None
+        return None, None
 
 
 def my_share(args, rank, world):
@@ -276,6 +237,7 @@ def run_rank(args):
         value = total * args.steps / elapsed
         launch_ms = ev_ms / args.steps  # one hot launch = one abc_hip_mul_relin over this rank's B pairs
         achieved = (ALGO_BYTES * B) / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(B)
         line = {
             "metric": "homomorphic mul+relin/sec, CKKS N=2^14", "value": value, "unit": "mul+relin/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -285,7 +247,10 @@ def run_rank(args):
                        "total_batch": total, "batch_rank0": B,
                        "sharding": "independent ciphertext pairs per rank, result gather only"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(B),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         # SURVEY.md section 8d's second accounting: relin key counted as cache-resident across the batch (3 MiB / op)
+                         "frac_key_resident": achieved / HBM_PEAK_GBS * ALGO_BYTES_KEY_RESIDENT / ALGO_BYTES,
+                         "algorithmic_bytes_per_unit": ALGO_BYTES, "algorithmic_bytes_per_unit_key_resident": ALGO_BYTES_KEY_RESIDENT,
                          "kernel": "abc_hip_mul_relin (rank 0's launch) = k_split2_tensor_pass0_fp + k_split2_tailmac_fp (special prime) + "
                                    "k_split3_pass_fp + k_split4_main_fp (dominant), DESIGN.md section 4",
                          "algorithmic_bytes_per_launch": ALGO_BYTES * B, "launch_ms": launch_ms},
@@ -322,7 +287,10 @@ def run_rank(args):
             for _ in range(5):
                 g60.op("mul_relin", *p6, L, C.c_size_t(B60))
             torch.cuda.synchronize()
-            line["value_60bit_primes"] = 5 * B60 / (time.perf_counter() - t6)
+            v60 = 5 * B60 / (time.perf_counter() - t6)
+            line["value_60bit_primes"] = v60
+            line["value_60bit_primes_detail"] = {"value": v60, "unit": "mul+relin/s", "frac": v60 * ALGO_BYTES / (HBM_PEAK_GBS * 1e9),
+                                                 "workload": "CKKS N=16384 {60,40,40,40 | 60}: integer kernels for the 60-bit primes, batch %d" % B60}
             o60 = om.Oracle(om.CKKS, N, p60)
             o60.keygen(0xABC00001)
             if not np.array_equal(o60.mul_relin(a6[B60 - 1].cpu().numpy().view(np.uint64), b6[B60 - 1].cpu().numpy().view(np.uint64)),
@@ -352,7 +320,10 @@ def run_rank(args):
             for _ in range(5):
                 gb.op("mul_relin", *pb, Lb, C.c_size_t(Bb))
             torch.cuda.synchronize()
-            line["value_bfv_default_ring"] = {"value": 5 * Bb / (time.perf_counter() - tb), "unit": "mul+relin/s",
+            vb = 5 * Bb / (time.perf_counter() - tb)
+            algo_b = 8 * nb * (6 * Lb + 2 * Lb * (Lb + 1))  # SURVEY.md section 8d's formula at L = 8: 25.2 MB
+            line["value_bfv_default_ring"] = {"value": vb, "unit": "mul+relin/s", "frac": vb * algo_b / (HBM_PEAK_GBS * 1e9),
+                                              "algorithmic_bytes_per_unit": algo_b,
                                               "workload": "BFV BFVDefault(16384) (8 data limbs + special), t = Batching(16384, 20), batch 256"}
             ob_ = om.Oracle(om.BFV, nb, list(gb.primes), gb.t)
             ob_.keygen(0xABC00001)

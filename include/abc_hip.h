@@ -149,9 +149,13 @@ int abc_hip_mod_switch(abc_hip_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, 
  * Everything enqueued on the context between begin and end is recorded instead of executed; the sequence must have
  * run once eagerly before (so that no scratch allocation happens while capturing) and may only use device pointers
  * that stay valid for every launch.  abc_hip_encrypt / abc_hip_keygen / *_h2d / *_d2h are not capturable.
- * Buffers: abc_hip_malloc inside a capture is served from the cache only (never the driver), and every buffer the recorded
- * sequence touched is pinned to the graph until abc_hip_graph_destroy -- freeing one earlier parks it instead of recycling
- * it, so a replay can never run over memory that has been handed to someone else.  A buffer that existed before the capture
+ * Buffers: abc_hip_malloc inside a capture is served from the cache only (never the driver).  Every buffer the recorded
+ * sequence can have touched is pinned to the graph until abc_hip_graph_destroy: the blocks the capture itself allocated or
+ * freed, and EVERY abc_hip_malloc block of this context that is still out with the caller when abc_hip_graph_end runs (so an
+ * operand that existed before the capture and is freed only after it -- a cached plaintext, an input -- is covered too).
+ * Freeing a pinned block parks it instead of recycling it, so a replay can never run over memory that has been handed to
+ * someone else; a block pinned by several graphs returns to the cache when the last of them is destroyed.  Memory that did not
+ * come from abc_hip_malloc is the caller's to keep alive.  A buffer that existed before the capture
  * and is freed inside it is an INPUT of the circuit: it keeps its address and contents are the caller's to refresh before a
  * replay (HipCiphertextFactory::rewriteCiphertext). */
 int abc_hip_graph_begin(abc_hip_ctx *ctx);

@@ -238,6 +238,20 @@ int main() {
       auto out = rt.getOutput("y = r;");
       expectPrefix(outputOf(f, out, "y"), expect(d1, d2));
     }
+    // the recording multiplies by the cached plaintext of k: more distinct constants than the factory's plaintext cache holds,
+    // encoded eagerly afterwards, evict that entry -- its block must stay parked for the graph, not be recycled under it
+    {
+      auto pile = f.createCiphertext(d1);
+      for (int v = 0; v < 40; ++v) {
+        pile->multiplyPlainInplace(Cleartext<int>(std::vector<int>{v + 3, 1, v + 5}));
+        pile = f.createCiphertext(d1);  // fresh ciphertext every round: freed blocks of the plaintext's size get reused
+      }
+      rt.setInput("a", a2);
+      rt.setInput("b", b2);
+      rt.replay();
+      auto out = rt.getOutput("y = r;");
+      expectPrefix(outputOf(f, out, "y"), expect(a2, b2));
+    }
     // a program that encrypts inside cannot be recorded: clean error, the factory stays usable
     CircuitRuntime bad(f, "secret int a = {1, 2};");
     EXPECT_THROWS(bad.compile("secret int t = {4, 5}; a = a +++ t;"));
