@@ -46,6 +46,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_galois_fusion = env_on("ABC_HIP_NO_GALOIS_FUSION");
   if (const char *e = std::getenv("ABC_HIP_CHUNK")) s.chunk = (size_t)std::atol(e);
   if (const char *e = std::getenv("ABC_HIP_FEW_LIMBS")) s.few_limbs = (size_t)std::atol(e);
+  if (const char *e = std::getenv("ABC_HIP_LEAN_LIMIT")) s.lean_limit = (size_t)std::atol(e);
   if (const char *e = std::getenv("ABC_HIP_PASS0_TARGET_LIMIT")) s.pass0_target_limit = (size_t)std::atol(e);
   if (const char *e = std::getenv("ABC_HIP_BFV_SCRATCH_MB")) s.bfv_scratch_mb = (size_t)std::atol(e);
   if (const char *e = std::getenv("ABC_HIP_LANE_OFFSET_US")) s.lane_offset_us = (unsigned)std::atoi(e);

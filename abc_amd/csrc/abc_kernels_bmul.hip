@@ -285,7 +285,8 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
 
 // ---- host side ----
 bool bmul_applies(const abc_hip_ctx *c) {
-  return c->scheme == 1 && c->logn == 14 && c->use_fp && c->behz_fp && !c->sw.no_bmul && c->L == 8 && c->nB == 8 && c->K == c->L + 1 &&
+  return c->scheme == 1 && c->logn == 14 && c->use_fp && c->behz_fp && !c->sw.no_bmul && !c->sw.no_split && !c->sw.no_fused && c->L == 8 &&
+         c->nB == 8 && c->K == c->L + 1 &&
          bsplit_applies(c, c->L);
 }
 

@@ -1716,7 +1716,7 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
       if (split && !c->sw.no_split2 && nl <= 12) {  // second-generation split kernels: three launches, 84 limb transfers
         // few ciphertexts in flight: the 139 KiB workgroups of the tensor kernel would leave most CUs idle for its whole
         // duration; the block-wise inverse tails + register cross pass of abc_kernels_gsplit.hip spread over the chip instead
-        const bool lean = !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= 96;  // measured at nl = 4: +5 % at 16 pairs, even at 32, -5 % at 48
+        const bool lean = !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= c->sw.lean_limit;  // measured at nl = 4: +5 % at 16 pairs, even at 32, -5 % at 48
         const int pack = pack_half_done(c, nl);
         if (lean)
           gsplit_front14(st, c, cc, nl, 0, a + off * ctw, b + off * ctw, 0, (double *)s.coef, (double *)s.dec, 0u, pack);
@@ -1811,7 +1811,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     if constexpr (LB == 14) {
       split = all_fp(c) && !c->sw.no_split;
       const int pack = (ckks && use2) ? pack_half_done(c, nl) : 0;
-      if (split && ckks && use2 && !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= 96)
+      if (split && ckks && use2 && !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= c->sw.lean_limit)
         gsplit_front14(st, c, cc, nl, 1, tg, nullptr, target_stride, (double *)s.coef, (double *)s.dec, gelt, pack);
       else if (split && ckks)
         hipLaunchKernelGGL((gelt ? k_fused_operand_pass0_fp<LB, true, true> : k_fused_operand_pass0_fp<LB, true, false>),
