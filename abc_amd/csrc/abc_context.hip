@@ -29,8 +29,6 @@ void read_switches(abc_hip_ctx *c) {
   abc_hip_ctx::Switches s;
   s.no_fused = env_on("ABC_HIP_NO_FUSED");
   s.no_split = env_on("ABC_HIP_NO_SPLIT");
-  s.no_split2 = env_on("ABC_HIP_NO_SPLIT2");
-  s.no_split3 = env_on("ABC_HIP_NO_SPLIT3");
   s.no_split4 = env_on("ABC_HIP_NO_SPLIT4");
   s.no_isplit = env_on("ABC_HIP_NO_ISPLIT");
   s.no_gsplit = env_on("ABC_HIP_NO_GSPLIT");
@@ -39,10 +37,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_pack = env_on("ABC_HIP_NO_PACK");
   s.no_bmul = env_on("ABC_HIP_NO_BMUL");
   s.no_lean_front = env_on("ABC_HIP_NO_LEAN_FRONT");
-  s.split4_special = env_on("ABC_HIP_SPLIT4_SPECIAL");
-  s.no_tensor_decomp = env_on("ABC_HIP_NO_TENSOR_DECOMP");
   s.no_tensor_intt = env_on("ABC_HIP_NO_TENSOR_INTT");
-  s.tailmac_serial = env_on("ABC_HIP_TAILMAC_SERIAL");
   s.no_galois_fusion = env_on("ABC_HIP_NO_GALOIS_FUSION");
   if (const char *e = std::getenv("ABC_HIP_CHUNK")) s.chunk = (size_t)std::atol(e);
   if (const char *e = std::getenv("ABC_HIP_FEW_LIMBS")) s.few_limbs = (size_t)std::atol(e);

@@ -43,9 +43,13 @@ __device__ __forceinline__ u64 dot_mod(int n, FA a, FB b, const Mod &m) {
 // back below 2q after every fourth term where 8q could pass 2^64 (q of 59..61 bits: the BEHZ auxiliary primes);
 // smaller moduli take up to 32 terms unreduced.  Returns a lazy value: < 2q if FLUSH else < 2nq (callers feed it to
 // mul_shoup, which accepts any 64-bit operand, or reduce it with reduce64 / canon_lazy2).
-template <class FA, class FW, class FS>
-__device__ __forceinline__ u64 dot_shoup_lazy(int n, FA a, FW w, FS ws, const Mod &m) {
+// NN > 0: the term count as a compile-time constant (NN == n): the loop then unrolls before the callers' register arrays are
+// lowered -- with a run-time bound the arrays behind the lambdas were indexed dynamically and lived in scratch memory
+// (k_behz_floor<8, 8>: 100 bytes per lane).
+template <int NN = 0, class FA, class FW, class FS>
+__device__ __forceinline__ u64 dot_shoup_lazy(int n_rt, FA a, FW w, FS ws, const Mod &m) {
   const bool flush = m.bits > 58;
+  const int n = NN ? NN : n_rt;
   u64 acc = 0;
 #pragma unroll
   for (int i = 0; i < n; i++) {
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void k_behz_extend(DevCtx c, const u64 *in, co
     for (int j = 0; j < nBsk; j++) {
       const Mod m = mod_at(c, c.id_bsk + j);
       const ABC_CONST_AS u64 *row = row_after(&k.q_to_bsk[j][0], dep), *row_s = row_after(&k.q_to_bsk_s[j][0], dep);
-      const u64 conv = dot_shoup_lazy(L, [&](int i) { return tmp[i]; }, [&](int i) { return row[i]; },
+      const u64 conv = dot_shoup_lazy<LT>(L, [&](int i) { return tmp[i]; }, [&](int i) { return row[i]; },
                                       [&](int i) { return row_s[i]; }, m);  // < 2p
       u64 r = r32;
       if (r32 >= 0x80000000u) r += m.q - 0x100000000ull;  // centred representative of r mod m~
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, con
     for (int j = 0; j < nBsk; j++) {
       const Mod m = mod_at(c, c.id_bsk + j);
       const ABC_CONST_AS u64 *row = row_after(&k.q_to_bsk[j][0], dep), *row_s = row_after(&k.q_to_bsk_s[j][0], dep);
-      const u64 conv = dot_shoup_lazy(L, [&](int i) { return tq[i]; }, [&](int i) { return row[i]; },
+      const u64 conv = dot_shoup_lazy<LT>(L, [&](int i) { return tq[i]; }, [&](int i) { return row[i]; },
                                       [&](int i) { return row_s[i]; }, m);
       // (dB*t - conv) * q^-1 = dB*(t q^-1) - conv*q^-1   (both constants carry Shoup quotients)
       const u64 xb = mul_shoup(dB[(p * nBsk + j) * c.n + x], k.tinvq_bsk[j], k.tinvq_bsk_s[j], m.q);
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, con
     u64 tb[LT ? NBT : kMaxLimbs];
 #pragma unroll
     for (int b2 = 0; b2 < nB; b2++) tb[b2] = mul_shoup(fl[b2], k.inv_punct_B[b2], k.inv_punct_B_s[b2], mod_at(c, c.id_bsk + b2).q);
-    const u64 msk_conv = canon_dot(dot_shoup_lazy(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_msk[b2]; },
+    const u64 msk_conv = canon_dot(dot_shoup_lazy<NBT>(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return k.B_to_msk[b2]; },
                                                   [&](int b2) { return k.B_to_msk_s[b2]; }, msk), msk);
     const u64 alpha = mul_shoup(sub_mod(msk_conv, fl[nB], msk.q), k.inv_B_mod_msk, k.inv_B_mod_msk_s, msk.q);
     const bool neg = alpha > (msk.q >> 1);
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void k_behz_floor(DevCtx c, const u64 *dq, con
     for (int i = 0; i < L; i++) {
       const Mod m = mod_at(c, i);
       const ABC_CONST_AS u64 *row = row_after(&k.B_to_q[i][0], dep), *row_s = row_after(&k.B_to_q_s[i][0], dep);
-      u64 v = dot_shoup_lazy(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return row[b2]; },
+      u64 v = dot_shoup_lazy<NBT>(nB, [&](int b2) { return tb[b2]; }, [&](int b2) { return row[b2]; },
                              [&](int b2) { return row_s[b2]; }, m);
       // +- alpha * B: one more lazy term (the subtraction as 2q - term keeps the sum non-negative)
       const u64 ab = mul_shoup_lazy(neg ? msk.q - alpha : alpha, k.B_mod_q[i], k.B_mod_q_s[i], m.q);

@@ -317,23 +317,6 @@ struct TensorFront {
 };
 
 template <int LB>
-__global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_intt_fp(DevCtx c, const u64 *__restrict__ a,
-                                                                         const u64 *__restrict__ b, u64 *__restrict__ c01,
-                                                                         u64 *__restrict__ c2coef, u64 *__restrict__ c2ntt, int nl) {
-  __shared__ double lds[lds_words(LB)];
-  const int j = blockIdx.x % nl;
-  const size_t ct = blockIdx.x / nl;
-  const size_t N = (size_t)1 << LB;
-  const Mod m = mod_at(c, j);
-  const FpTable t = fp_table(c, j);
-  TensorFront front(a, b, c01, c2ntt, ct, j, nl, N, m);
-  u64 *__restrict__ dcoef = c2coef + (ct * nl + j) * N;
-  ntt_inv_block_a<LB, FpArith>(
-      lds, [&](int r, int i) { return front(r, i); },
-      [&](int, int i, double v) { dcoef[i] = fp_to_canon(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv); }, t, m, 0, 0);
-}
-
-template <int LB>
 __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_intt_fp(DevCtx c, const u64 *__restrict__ src, size_t src_stride,
                                                                           u64 *__restrict__ dst, int nl) {
   __shared__ double lds[lds_words(LB)];
@@ -539,51 +522,9 @@ __device__ __forceinline__ void store_half_done(double *__restrict__ dst, double
 // A 2^14-point forward transform is a radix-16 pass over stride-1024 elements (stages 0..3, no LDS: the sixteen
 // operands of a lane are exactly what the inverse transform's last pass leaves in its registers) followed by
 // sixteen independent 1024-point transforms (stages 4..13) that one wavefront each completes in 8.5 KiB of LDS.
-// K1s does the LDS-resident part (tensor product, inverse transform of c2_j) and the register pass of the nl
-// forward transforms, and stores the half-done limbs as raw doubles; K2s finishes them block by block and
-// multiplies into the key on the fly.  K2s workgroups are single wavefronts (no 128-VGPR ceiling, so both
-// accumulators fit in registers, and a dozen of them share a CU, so their HBM phases overlap each other's
-// arithmetic -- which a 1024-thread, 139 KiB workgroup cannot do with itself).
-template <int LB>
-__global__ __launch_bounds__((1 << LB) / 16) void k_fused_tensor_pass0_fp(DevCtx c, const u64 *__restrict__ a,
-                                                                          const u64 *__restrict__ b, u64 *__restrict__ c01,
-                                                                          u64 *__restrict__ c2ntt, double *__restrict__ part, int nl) {
-  static_assert(LB == 14, "split transforms are laid out for N = 2^14");
-  __shared__ double lds[lds_words(LB)];
-  const int j = blockIdx.x % nl;
-  const size_t ct = blockIdx.x / nl;
-  const size_t N = (size_t)1 << LB;
-  double src[16];
-  {
-    const Mod m = mod_at(c, j);
-    const FpTable t = fp_table(c, j);
-    TensorFront front(a, b, c01, c2ntt, ct, j, nl, N, m);
-    ntt_inv_block_a<LB, FpArith>(
-        lds, [&](int r, int i) { return front(r, i); },
-        // canonical [0, q_j) as a double: the value SEAL's decomposition reduces modulo the other primes
-        [&](int r, int, double v) {
-          const double w = fp_centre(fp_mul_lazy(v, m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
-          src[r] = w < 0.0 ? w + m.qd : w;
-        },
-        t, m, 0, 0);
-  }
-  const int tid = threadIdx.x;
-  const int hi0[1] = {0};
-  for (int I = 0; I <= nl; I++) {
-    if (I == j) continue;
-    const int ki = (I == nl) ? c.K - 1 : I;
-    const Mod m = mod_at(c, ki);
-    const FpTable t = fp_table(c, ki);
-    const FpK kk = FpArith::consts(m);
-    double y[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) y[k] = src[k];
-    fwd_pass<FpArith, LB, 0, 4>(y, hi0, t, kk, 0, 0);
-    double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * N;
-#pragma unroll
-    for (int k = 0; k < 16; k++) dst[(k << 10) + tid] = y[k];
-  }
-}
+// The first kernel of a sequence does the LDS-resident part (tensor product or operand, inverse transform of limb j) and the
+// register pass of the forward transforms, and stores the half-done limbs (raw doubles or packed, abc_ntt.hpp); the later
+// kernels finish them block by block and multiply into the key on the fly.
 
 // K1s for a general key switch.  CKKS (the operand arrives in NTT form): inverse transform of limb j in LDS, then the
 // register pass modulo every other key prime.  BFV (coefficient form): no LDS at all, the register pass modulo every key
@@ -635,151 +576,21 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCt
   }
 }
 
-// K2s: workgroup (ct, I, block): x_J = stages 4..13 of the half-done limb (ct, I, J) on this 1024-point block (for
-// J = I, CKKS: the operand's own NTT form), acc_c += x_J * key[J][c][I]; canonical sums to ksacc / tsp.
-template <bool GAL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_fused_tailmac_fp(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ ntt,
-                                                         size_t ntt_stride, const u64 *__restrict__ key, u64 *__restrict__ ksacc,
-                                                         u64 *__restrict__ tsp, int nl, u32 gelt) {
-  __shared__ double lds[lds_words(10)];
-  const int blk = blockIdx.x & 15;
-  const int I = (blockIdx.x >> 4) % (nl + 1);
-  const size_t ct = (blockIdx.x >> 4) / (nl + 1);
-  const size_t N = (size_t)c.n;
-  const int ki = (I == nl) ? c.K - 1 : I;
-  const Mod m = mod_at(c, ki);
-  const FpTable t = fp_table(c, ki);
-  const double q = m.qd, qinv = m.qinv;
-  const int tid = threadIdx.x;
-  double acc0[16], acc1[16];
-#pragma unroll
-  for (int r = 0; r < 16; r++) acc0[r] = acc1[r] = 0.0;
-  for (int J = 0; J < nl; J++) {
-    const u64 *__restrict__ k0 = key + (((size_t)J * 2 + 0) * c.K + ki) * N + ((size_t)blk << 10);
-    const u64 *__restrict__ k1 = key + (((size_t)J * 2 + 1) * c.K + ki) * N + ((size_t)blk << 10);
-    auto accum = [&](int r, int i, double v) {
-      acc0[r] += fp_mulmod(v, fp_from_u64(k0[i]), q, qinv);
-      acc1[r] += fp_mulmod(v, fp_from_u64(k1[i]), q, qinv);
-    };
-    if (ntt && J == I) {
-      const u64 *__restrict__ xl = ntt + ct * ntt_stride + (size_t)J * N;  // whole limb: a rotation gathers across blocks
-#pragma unroll
-      for (int g = 0; g < 4; g++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int i = 4 * (tid + 64 * g) + k;
-          accum(4 * g + k, i, fp_from_u64(xl[galois_ntt_src<GAL>((u32)((blk << 10) + i), gelt, c.logn)]));
-        }
-    } else {
-      const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
-      wave_sync();  // single wavefront: the previous transform's LDS reads are ordered before these writes
-      ntt_fwd_block_a<10, FpArith>(
-          lds, [&](int, int i) { return fp_centre(src[i], q, qinv); }, accum, t, m, 4, blk);
-    }
-  }
-  u64 *__restrict__ o0 = (I == nl) ? tsp + (ct * 2 + 0) * N : ksacc + ((ct * 2 + 0) * nl + I) * N;
-  u64 *__restrict__ o1 = (I == nl) ? tsp + (ct * 2 + 1) * N : ksacc + ((ct * 2 + 1) * nl + I) * N;
-#pragma unroll
-  for (int g = 0; g < 4; g++)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const size_t i = ((size_t)blk << 10) + 4 * (tid + 64 * g) + k;
-      o0[i] = fp_to_canon(acc0[4 * g + k], q, qinv);
-      o1[i] = fp_to_canon(acc1[4 * g + k], q, qinv);
-    }
-}
-
-// K2s, cooperative form: one workgroup of nl wavefronts per (ct, I, block); wavefront J finishes limb J's block (or
-// takes the diagonal operand), multiplies by its two key slices and adds the products into two LDS accumulators
-// (ds_add_f64: sums of integer-valued doubles below 2^53 are exact in any order).  The nl operand loads of an item are
-// in flight together and no wavefront carries accumulators, so it runs at four wavefronts per SIMD.
-template <bool GAL>
-__global__ __launch_bounds__(1024) void k_fused_tailmac_coop_fp(DevCtx c, const double *__restrict__ part,
-                                                                const u64 *__restrict__ ntt, size_t ntt_stride,
-                                                                const u64 *__restrict__ key, u64 *__restrict__ ksacc,
-                                                                u64 *__restrict__ tsp, int nl, u32 gelt) {
-  extern __shared__ double dyn[];
-  // LDS: max(nl, 2) transform buffers of 8.5 KiB; once every wavefront's transform is done the first two double as the
-  // two accumulators ([4][256]: k, p for element 4p + k of the block: lanes walk p, conflict-free), so four workgroups
-  // (16 wavefronts) fit a CU
-  const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  double *lds = dyn + J * lds_words(10);
-  double *acc0 = dyn, *acc1 = dyn + lds_words(10);
-  const int blk = blockIdx.x & 15;
-  const int I = (blockIdx.x >> 4) % (nl + 1);
-  const size_t ct = (blockIdx.x >> 4) / (nl + 1);
-  const size_t N = (size_t)c.n;
-  const int ki = (I == nl) ? c.K - 1 : I;
-  const Mod m = mod_at(c, ki);
-  const FpTable t = fp_table(c, ki);
-  const double q = m.qd, qinv = m.qinv;
-  double x[16];  // this wavefront's limb on the block, final transform layout: slot 4g + k = element 4 (lane + 64 g) + k
-  if (ntt && J == I) {
-    const u64 *__restrict__ xl = ntt + ct * ntt_stride + (size_t)J * N;  // whole limb: a rotation gathers across blocks
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        x[4 * g + k] = fp_from_u64(xl[galois_ntt_src<GAL>((u32)((blk << 10) + 4 * (lane + 64 * g) + k), gelt, c.logn)]);
-  } else {
-    const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * N + ((size_t)blk << 10);
-    ntt_fwd_block_a<10, FpArith>(
-        lds, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int r, int, double v) { x[r] = v; }, t, m, 4, blk, lane);
-  }
-  __syncthreads();  // every transform has left LDS
-  for (int i = threadIdx.x; i < 1024; i += blockDim.x) acc0[i] = acc1[i] = 0.0;
-  __syncthreads();
-  {
-    const u64 *__restrict__ k0 = key + (((size_t)J * 2 + 0) * c.K + ki) * N + ((size_t)blk << 10);
-    const u64 *__restrict__ k1 = key + (((size_t)J * 2 + 1) * c.K + ki) * N + ((size_t)blk << 10);
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int p = lane + 64 * g;
-      const u64x2 a0 = reinterpret_cast<const u64x2 *>(k0 + 4 * p)[0], a1 = reinterpret_cast<const u64x2 *>(k0 + 4 * p)[1];
-      const u64x2 b0 = reinterpret_cast<const u64x2 *>(k1 + 4 * p)[0], b1 = reinterpret_cast<const u64x2 *>(k1 + 4 * p)[1];
-      const u64 kk0[4] = {a0.x, a0.y, a1.x, a1.y}, kk1[4] = {b0.x, b0.y, b1.x, b1.y};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int slot = (k << 8) + p;
-        __hip_atomic_fetch_add(acc0 + slot, fp_mulmod(x[4 * g + k], fp_from_u64(kk0[k]), q, qinv), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(acc1 + slot, fp_mulmod(x[4 * g + k], fp_from_u64(kk1[k]), q, qinv), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-  }
-  __syncthreads();
-  u64 *__restrict__ o0 = ((I == nl) ? tsp + (ct * 2 + 0) * N : ksacc + ((ct * 2 + 0) * nl + I) * N) + ((size_t)blk << 10);
-  u64 *__restrict__ o1 = ((I == nl) ? tsp + (ct * 2 + 1) * N : ksacc + ((ct * 2 + 1) * nl + I) * N) + ((size_t)blk << 10);
-  for (int p = threadIdx.x; p < 256; p += blockDim.x) {
-    u64x2 r;
-    r.x = fp_to_canon(acc0[p], q, qinv); r.y = fp_to_canon(acc0[256 + p], q, qinv);
-    *reinterpret_cast<u64x2 *>(o0 + 4 * p) = r;
-    r.x = fp_to_canon(acc0[512 + p], q, qinv); r.y = fp_to_canon(acc0[768 + p], q, qinv);
-    *reinterpret_cast<u64x2 *>(o0 + 4 * p + 2) = r;
-    r.x = fp_to_canon(acc1[p], q, qinv); r.y = fp_to_canon(acc1[256 + p], q, qinv);
-    *reinterpret_cast<u64x2 *>(o1 + 4 * p) = r;
-    r.x = fp_to_canon(acc1[512 + p], q, qinv); r.y = fp_to_canon(acc1[768 + p], q, qinv);
-    *reinterpret_cast<u64x2 *>(o1 + 4 * p + 2) = r;
-  }
-}
-
-
-// ---- split transforms, second generation ("split2": N = 2^14, CKKS, every key prime < 2^50) ----------------------------
-// Same arithmetic as the kernels above, 84 limb transfers per multiply instead of 104 and three launches instead of four:
-//   * the tensor kernel reads only a1, b1 (c2 = a1 b1 is all the key switch needs) and writes only the half-done limbs;
-//   * the tail / inner-product kernel computes the diagonal operand c2_I = a1 b1 itself, block by block, together with
-//     c0 = a0 b0 and c1 = a0 b1 + a1 b0, and folds q_sp * c0, q_sp * c1 into the accumulators:
-//         (acc + q_sp c - NTT(t)) q_sp^-1  =  (acc - NTT(t)) q_sp^-1 + c      (mod q_I)
-//     so neither c0, c1 nor c2's NTT form ever travel through scratch (8 + 8 + 4 + 4 limbs), and `out` may still alias an
-//     operand (a and b are last read by this kernel, `out` is first written by the next one);
-//   * sums over J are formed in registers: wavefront J finishes its limb, parks it in its LDS buffer, and after one
-//     barrier every thread owns two adjacent coefficients of the block for all J (16-byte key loads, fully coalesced
-//     16-byte stores, no LDS atomics);
-//   * the workgroups of the special prime also run the ten block-local stages of its inverse transform, so the separate
-//     inverse-transform kernel is gone: the mod-down kernel starts with the remaining radix-16 pass on the sixteen
-//     stride-1024 values it loads anyway.
+// ---- the split sequence of the hot call (N = 2^14, CKKS, every key prime < 2^50): four launches, 84 limb transfers -----------
+//   K1  k_split2_tensor_pass0_fp (multiply) / k_fused_operand_pass0_fp (rotation, relinearise): reads only a1, b1 (c2 = a1 b1 is
+//       all the key switch needs), inverse transform in LDS, register pass modulo every other key prime -> half-done limbs
+//   K2a k_split_special_fp: the special prime's inner product and the block-local part of its inverse transform
+//   K2b k_split3_pass_fp (registers only): last radix-16 pass of that inverse transform, N^-1, + q_sp/2, then for every data prime
+//       q_j the first radix-16 pass of the forward transform of (t mod q_j): half-done mod-down limbs
+//   K2c k_split4_main_fp (up to five data limbs) / k_split3_main_fp, per (ct, data prime I, block): nl - 1 wavefronts finish the
+//       decomposition limbs, two more the mod-down limbs of K2b on the same block, then every thread forms, for two adjacent
+//       coefficients,   out_c = (sum_J x_J key_J,c + q_sp c_c - NTT_I(t_c)) q_sp^-1   (mod q_I)
+//       with the diagonal operand c2_I = a1 b1 and c0 = a0 b0, c1 = a0 b1 + a1 b0 computed right there from a and b and folded in
+//       as q_sp c:  (acc + q_sp c - NTT(t)) q_sp^-1 = (acc - NTT(t)) q_sp^-1 + c.  Neither c0, c1 nor c2's NTT form ever travel
+//       through scratch, the accumulators never leave the CU, sums over J are formed in registers (no LDS atomics), and `out`
+//       may alias an operand (a and b are last read here, by the thread that then writes those words).
+// (Earlier generations -- LDS-atomic tail kernels, the LDS-resident mod-down, an LDS-table twin of K2a -- were measured in
+// rounds 1 and 2 and are gone: DESIGN.md section 4.)
 template <int LB>
 __global__ __launch_bounds__((1 << LB) / 16) void k_split2_tensor_pass0_fp(DevCtx c, const u64 *__restrict__ a,
                                                                            const u64 *__restrict__ b, double *__restrict__ part,
@@ -821,84 +632,46 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_split2_tensor_pass0_fp(DevCt
   }
 }
 
-// MODE 0: ciphertext x ciphertext multiply (opa = a, opb = b: [ct][2][nl][N]).
-// MODE 1: key switch of an operand in NTT form at opa + ct * opa_stride (limb I = the diagonal term), optional addend
-//         (c0, c1) at opb + ct * opb_stride, c1 only if add_c1; GAL: the Galois permutation of a rotation folded into both.
-// NL > 0: compile-time limb count (the loop over J unrolls, all its loads are issued together); NL = 0: any nl <= 12.
-template <int MODE, bool GAL, int NL>
-__global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split2_tailmac_fp(DevCtx c, const double *__restrict__ part,
-                                                                          const u64 *__restrict__ opa, const u64 *__restrict__ opb,
-                                                                          size_t opa_stride, size_t opb_stride, int add_c1,
-                                                                          const u64 *__restrict__ key, u64 *__restrict__ ksacc,
-                                                                          double *__restrict__ tsp_half, int nl_rt, u32 gelt,
-                                                                          int only_special) {
+// K2a, the special prime's share of the key inner product (grid (ct, block); nl wavefronts): wavefront J finishes stages 4..13 of
+// the half-done limb (ct, special prime, J) on this 1024-point block and parks it in LDS; after one barrier every thread sums, for
+// two adjacent coefficients, x_J key[J][c][special] over J in registers; the two sums go back to LDS and wavefronts 0 and 1 run
+// the ten block-local stages of the special-prime limb's INVERSE transform on them -> tsp_half (raw doubles); k_split3_pass_fp
+// does the remaining radix-16 pass.  NL > 0: compile-time limb count (the loop over J unrolls, all its loads are issued
+// together); NL = 0: any nl <= 12.
+template <int NL>
+__global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split_special_fp(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
+                                                                         double *__restrict__ tsp_half, int nl_rt) {
   extern __shared__ double dyn[];  // max(nl, 2) buffers of one 1024-point block each
   const int nl = NL ? NL : nl_rt;
   const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int blk = blockIdx.x & 15;
-  // only_special (split3): grid = (ct, block), every workgroup works modulo the special prime
-  const int I = only_special ? nl : (int)((blockIdx.x >> 4) % (nl + 1));
-  const size_t ct = only_special ? (size_t)(blockIdx.x >> 4) : (size_t)((blockIdx.x >> 4) / (nl + 1));
+  const size_t ct = (size_t)(blockIdx.x >> 4);
   const size_t N = (size_t)c.n, base = (size_t)blk << 10;
-  const int ki = (I == nl) ? c.K - 1 : I;
+  const int ki = c.K - 1;
   const Mod m = mod_at(c, ki);
   const FpTable t = fp_table(c, ki);
   const double q = m.qd, qinv = m.qinv;
-  const bool diag = (I < nl);  // limb I of the operand is already in NTT form modulo q_I: no transform for J = I
-  if (!(diag && J == I)) {
+  {
     double *buf = dyn + J * lds_words(10);
-    const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * (size_t)c.ps + base;
+    const double *__restrict__ src = part + ((ct * (nl + 1) + nl) * nl + J) * (size_t)c.ps + base;
     ntt_fwd_block_a<10, FpArith>(
         buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk,
         lane);
   }
   __syncthreads();
-  const double spc = diag ? c.cst->special_c[I] : 0.0, spq = diag ? c.cst->special_cq[I] : 0.0;
-  const size_t pw = (size_t)nl * N;
   for (int e = 2 * (int)threadIdx.x; e < 1024; e += 2 * (int)blockDim.x) {  // this thread: coefficients e, e + 1 of the block
-    double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
+    double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
 #pragma unroll
     for (int Jx = 0; Jx < (NL ? NL : 12); Jx++) {
       if (!NL && Jx >= nl) break;
-      double x[2];
-      if (diag && Jx == I) {
-        if (MODE == 0) {
-          const u64 *pa = opa + ct * 2 * pw + (size_t)I * N + base + e, *pb = opb + ct * 2 * pw + (size_t)I * N + base + e;
-          const u64x2 a0 = *reinterpret_cast<const u64x2 *>(pa), a1 = *reinterpret_cast<const u64x2 *>(pa + pw);
-          const u64x2 b0 = *reinterpret_cast<const u64x2 *>(pb), b1 = *reinterpret_cast<const u64x2 *>(pb + pw);
-          const double x0[2] = {fp_from_u64(a0.x), fp_from_u64(a0.y)}, x1[2] = {fp_from_u64(a1.x), fp_from_u64(a1.y)};
-          const double y0[2] = {fp_from_u64(b0.x), fp_from_u64(b0.y)}, y1[2] = {fp_from_u64(b1.x), fp_from_u64(b1.y)};
-#pragma unroll
-          for (int k = 0; k < 2; k++) {
-            x[k] = fp_mulmod(x1[k], y1[k], q, qinv);
-            d0[k] = fp_mulmod(x0[k], y0[k], q, qinv);
-            d1[k] = fp_mulmod(x0[k], y1[k], q, qinv) + fp_mulmod(x1[k], y0[k], q, qinv);
-          }
-        } else {
-          const u64 *xl = opa + ct * opa_stride + (size_t)I * N;  // whole limb: a rotation gathers across blocks
-#pragma unroll
-          for (int k = 0; k < 2; k++) {
-            const u32 si = galois_ntt_src<GAL>((u32)(base + e + k), gelt, c.logn);
-            x[k] = fp_from_u64(xl[si]);
-            if (opb) {
-              const u64 *ad = opb + ct * opb_stride + (size_t)I * N;
-              d0[k] = fp_from_u64(ad[si]);
-              if (add_c1) d1[k] = fp_from_u64(ad[pw + si]);
-            }
-          }
-        }
-      } else {
-        const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
-        x[0] = v.x;
-        x[1] = v.y;
-      }
+      const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
       const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
       const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
-      s0[0] += fp_mulmod(x[0], fp_from_u64(k0.x), q, qinv);
-      s0[1] += fp_mulmod(x[1], fp_from_u64(k0.y), q, qinv);
-      s1[0] += fp_mulmod(x[0], fp_from_u64(k1.x), q, qinv);
-      s1[1] += fp_mulmod(x[1], fp_from_u64(k1.y), q, qinv);
+      s0[0] += fp_mulmod(v.x, fp_from_u64(k0.x), q, qinv);
+      s0[1] += fp_mulmod(v.y, fp_from_u64(k0.y), q, qinv);
+      s1[0] += fp_mulmod(v.x, fp_from_u64(k1.x), q, qinv);
+      s1[1] += fp_mulmod(v.y, fp_from_u64(k1.y), q, qinv);
       if (Jx == 7) {  // eight products of magnitude < q stay below 2^53; re-centre before adding more
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -907,108 +680,34 @@ __global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split2_tailmac_fp(DevCtx
         }
       }
     }
-    if (diag) {
-      // + q_sp * (c0, c1): the mod-down's division by q_sp turns it into + (c0, c1)
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        s0[k] += fp_mul_lazy(d0[k], spc, spq, q);
-        s1[k] += fp_mul_lazy(d1[k], spc, spq, q);
-      }
-      u64x2 r;
-      r.x = fp_to_canon(s0[0], q, qinv); r.y = fp_to_canon(s0[1], q, qinv);
-      *reinterpret_cast<u64x2 *>(ksacc + ((ct * 2 + 0) * nl + I) * N + base + e) = r;
-      r.x = fp_to_canon(s1[0], q, qinv); r.y = fp_to_canon(s1[1], q, qinv);
-      *reinterpret_cast<u64x2 *>(ksacc + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
-    } else {
-      // special prime: park the two sums (centred) in buffers 0 and 1; this thread has read its words of them already
-      f64x2 r;
-      r.x = fp_centre(s0[0], q, qinv); r.y = fp_centre(s0[1], q, qinv);
-      *reinterpret_cast<f64x2 *>(dyn + lds_pad(e)) = r;
-      r.x = fp_centre(s1[0], q, qinv); r.y = fp_centre(s1[1], q, qinv);
-      *reinterpret_cast<f64x2 *>(dyn + lds_words(10) + lds_pad(e)) = r;
-    }
+    // park the two sums (centred) in buffers 0 and 1; this thread has read its words of them already
+    f64x2 r;
+    r.x = fp_centre(s0[0], q, qinv); r.y = fp_centre(s0[1], q, qinv);
+    *reinterpret_cast<f64x2 *>(dyn + lds_pad(e)) = r;
+    r.x = fp_centre(s1[0], q, qinv); r.y = fp_centre(s1[1], q, qinv);
+    *reinterpret_cast<f64x2 *>(dyn + lds_words(10) + lds_pad(e)) = r;
   }
-  if (!diag) {  // workgroup-uniform
-    __syncthreads();
-    // stages 13..4 of the special-prime limb's inverse transform on this block, one wavefront per component
-    for (int comp = J; comp < 2; comp += nl) {
-      double *buf = dyn + comp * lds_words(10);
-      double *__restrict__ dst = tsp_half + (ct * 2 + comp) * (size_t)c.ps + base;
-      ntt_inv_block_a<10, FpArith>(
-          buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, 4, blk, lane);
-    }
+  __syncthreads();
+  for (int comp = J; comp < 2; comp += nl) {  // one wavefront per component
+    double *buf = dyn + comp * lds_words(10);
+    double *__restrict__ dst = tsp_half + (ct * 2 + comp) * (size_t)c.ps + base;
+    ntt_inv_block_a<10, FpArith>(
+        buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, 4, blk, lane);
   }
 }
 
-// mod-down: the last radix-16 pass of the special-prime limb's inverse transform on the sixteen stride-1024 values of a
-// lane, N^-1, + q_sp/2, canonical; then (as k_fused_ks_moddown_fp) the forward transform modulo q_j in LDS, subtract,
-// scale by q_sp^-1.  No addend: the tail kernel has folded it into the accumulators.
-template <int LB>
-__global__ __launch_bounds__((1 << LB) / 16) void k_split2_moddown_fp(DevCtx c, const u64 *__restrict__ ksacc,
-                                                                      const double *__restrict__ tsp_half, u64 *__restrict__ out,
-                                                                      int nl, int ncc) {
-  static_assert(LB == 14, "split transforms are laid out for N = 2^14");
-  __shared__ double lds[lds_words(LB)];
-  // the nl workgroups that read one special-prime polynomial are 8 apart in blockIdx: they share an XCD's L2
-  const unsigned per = 8u * (unsigned)nl;
-  const unsigned grp = blockIdx.x / per, rem = blockIdx.x % per;
-  const unsigned left = (unsigned)ncc - grp * 8u, gsz = left < 8u ? left : 8u;  // the last group may be ragged
-  const int j = (int)(rem / gsz);
-  const size_t cc = (size_t)grp * 8 + rem % gsz;  // ct*2 + comp
-  const size_t N = (size_t)1 << LB;
-  const int tid = threadIdx.x;
-  double x[16];
-  {
-    const Mod ms = mod_at(c, c.K - 1);
-    const FpTable ts = fp_table(c, c.K - 1);
-    const FpK ks = FpArith::consts(ms);
-    const double *__restrict__ src = tsp_half + cc * (size_t)c.ps;
-#pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = src[(k << 10) + tid];
-    FpArith::centre16(x, ks);
-    const int hi0[1] = {0};
-    inv_pass<FpArith, LB, 0, 4>(x, hi0, ts, ks, 0, 0);
-    const double half = (double)(ms.q >> 1);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const double w = fp_centre(fp_mul_lazy(x[k], ms.inv_n_c, ms.inv_n_cq, ms.qd) + half, ms.qd, ms.qinv);
-      x[k] = w < 0.0 ? w + ms.qd : w;  // canonical [0, q_sp): what SEAL reduces modulo q_j
-    }
-  }
-  const Mod m = mod_at(c, j);
-  const FpTable t = fp_table(c, j);
-  const u64 half = c.mods[c.K - 1].q >> 1;
-  const u64 hm = reduce64(half, m);
-  const double fix = hm ? (double)(m.q - hm) : 0.0;
-  const double inv = c.cst->inv_special_c[j], inv_q = c.cst->inv_special_cq[j];
-  const u64 *__restrict__ ks = ksacc + (cc * nl + j) * N;
-  u64 *__restrict__ o = out + (cc * nl + j) * N;
-  ntt_fwd_block_a<LB, FpArith>(
-      lds, [&](int r, int) { return x[r] + fix; },
-      [&](int, int i, double v) {
-        const double d = fp_from_u64(ks[i]) - v;
-        o[i] = fp_to_canon(fp_mul_lazy(d, inv, inv_q, m.qd), m.qd, m.qinv);
-      },
-      t, m, 0, 0);
-}
-
-template <int MODE, bool GAL>
-static void launch_split2_tailmac(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const u64 *opa, const u64 *opb,
-                                  size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *ksacc, double *tsp_half,
-                                  u32 gelt, int only_special = 0) {
-  const dim3 grid((unsigned)(cc * (only_special ? 1 : nl + 1) * 16)), block(64 * nl);
+static void launch_split_special(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const u64 *key, double *tsp_half) {
+  const dim3 grid((unsigned)(cc * 16)), block(64 * nl);
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
-#define ABC_TM2(NLV)                                                                                                            \
-  hipLaunchKernelGGL((k_split2_tailmac_fp<MODE, GAL, NLV>), grid, block, lds, st, c->dc, part, opa, opb, opa_stride, opb_stride, \
-                     add_c1, key, ksacc, tsp_half, nl, gelt, only_special)
+#define ABC_SP(NLV) hipLaunchKernelGGL((k_split_special_fp<NLV>), grid, block, lds, st, c->dc, part, key, tsp_half, nl)
   switch (nl) {
-    case 1: ABC_TM2(1); break;
-    case 2: ABC_TM2(2); break;
-    case 3: ABC_TM2(3); break;
-    case 4: ABC_TM2(4); break;
-    default: ABC_TM2(0); break;
+    case 1: ABC_SP(1); break;
+    case 2: ABC_SP(2); break;
+    case 3: ABC_SP(3); break;
+    case 4: ABC_SP(4); break;
+    default: ABC_SP(0); break;
   }
-#undef ABC_TM2
+#undef ABC_SP
 }
 
 // scratch limbs per ciphertext: coef L, ntt L, dec L(L+1), ksacc 2L, tsp 2, tlast 2, c01 2L
@@ -1030,16 +729,6 @@ static inline FusedScratch carve(u64 *base, size_t chunk, int nl, size_t N) {
 }
 
 
-// ---- third generation ("split3"): the mod-down moves into the tail kernel, no LDS-resident kernel after the first one ----
-//   K1  k_split2_tensor_pass0_fp / k_fused_operand_pass0_fp            (unchanged)
-//   K2a k_split2_tailmac_fp, special prime only: inner product modulo q_sp and the block-local part of its inverse transform
-//   K2b k_split3_pass_fp: per (ct, component), registers only: last radix-16 pass of that inverse transform, N^-1, + q_sp/2,
-//       then for every data prime q_j the first radix-16 pass of the forward transform of (t mod q_j): half-done limbs
-//   K2c k_split3_main_fp, per (ct, data prime I, block): nl - 1 wavefronts finish the decomposition limbs, two more finish the
-//       two half-done mod-down limbs of K2b on the same block, then every thread forms, for two adjacent coefficients,
-//           out_c = (sum_J x_J key_J,c + q_sp c_c - NTT_I(t_c))  q_sp^-1                                  (mod q_I)
-//       and stores the result: the accumulators never leave the CU (8 + 8 limbs), and the 139 KiB mod-down workgroups,
-//       whose load / compute / store phases did not overlap at all (T = T_HBM + T_VALU), are gone.
 template <int LB>
 __global__ __launch_bounds__(256) void k_split3_pass_fp(DevCtx c, const double *__restrict__ tsp_half, double *__restrict__ tpart, int nl,
                                                         int pack) {
@@ -1405,105 +1094,11 @@ bool split4_main_subset(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int m
 }
 
 
-// split4 twin of the special-prime workgroups of k_split2_tailmac_fp: LDS twiddle tables (forward and inverse), key slices
-// requested before the transforms, 512 threads (one coefficient pair each)
-template <int NL>
-__global__ __launch_bounds__(512, 2) void k_split4_special_fp(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
-                                                              double *__restrict__ tsp_half) {
-  extern __shared__ double dyn[];  // max(nl, 2) transform buffers, forward table, inverse table
-  static_assert(NL <= 8, "one wavefront per limb, eight wavefronts");
-  constexpr int nl = NL, NB = NL < 2 ? 2 : NL, NT = 512, PER = 2;
-  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  const int blk = blockIdx.x & 15;
-  const size_t ct = (size_t)(blockIdx.x >> 4);
-  const size_t N = (size_t)c.n, base = (size_t)blk << 10;
-  const int ki = c.K - 1;
-  const Mod m = mod_at(c, ki);
-  const FpTable t = fp_table(c, ki);
-  const double q = m.qd, qinv = m.qinv;
-  f64x2 *ltw = reinterpret_cast<f64x2 *>(dyn + NB * lds_words(10)), *litw = ltw + 1024;
-  f64x2 twv[PER], itwv[PER];
-  block_twiddles_fetch<10, f64x2, PER>(t.tw, 4, blk, (int)threadIdx.x, NT, twv);
-  const bool has_limb = W < nl;
-  const double *__restrict__ src = part + ((ct * (nl + 1) + nl) * nl + (has_limb ? W : 0)) * (size_t)c.ps + base;
-  double xin[16];
-  if (has_limb) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) xin[k] = src[(k << 6) + lane];
-  }
-  block_twiddles_fetch<10, f64x2, PER>(t.itw, 4, blk, (int)threadIdx.x, NT, itwv);
-  const int e = 2 * (int)threadIdx.x;
-  u64x2 k0[NL], k1[NL];
-#pragma unroll
-  for (int Jx = 0; Jx < NL; Jx++) {
-    k0[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
-    k1[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
-  }
-  block_twiddles_store<10, f64x2, PER>(ltw, (int)threadIdx.x, NT, twv);
-  block_twiddles_store<10, f64x2, PER>(litw, (int)threadIdx.x, NT, itwv);
-  __syncthreads();
-  if (has_limb) {
-    double *buf = dyn + W * lds_words(10);
-    auto ld = [&](int r, int) { return fp_centre(xin[r], q, qinv); };
-    auto st = [&](int, int i, double v) { buf[lds_pad(i)] = v; };
-    ntt_fwd_block_a<10, FpArith, decltype(ld), decltype(st), true>(buf, ld, st, t, m, 4, blk, lane, ltw);
-  }
-  __syncthreads();
-  double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
-#pragma unroll
-  for (int Jx = 0; Jx < NL; Jx++) {
-    const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
-    s0[0] += fp_mulmod(v.x, fp_from_u64(k0[Jx].x), q, qinv);
-    s0[1] += fp_mulmod(v.y, fp_from_u64(k0[Jx].y), q, qinv);
-    s1[0] += fp_mulmod(v.x, fp_from_u64(k1[Jx].x), q, qinv);
-    s1[1] += fp_mulmod(v.y, fp_from_u64(k1[Jx].y), q, qinv);
-  }
-  // park the two sums (centred) in buffers 0 and 1: a thread overwrites only the words it alone has read
-  f64x2 r;
-  r.x = fp_centre(s0[0], q, qinv); r.y = fp_centre(s0[1], q, qinv);
-  *reinterpret_cast<f64x2 *>(dyn + lds_pad(e)) = r;
-  r.x = fp_centre(s1[0], q, qinv); r.y = fp_centre(s1[1], q, qinv);
-  *reinterpret_cast<f64x2 *>(dyn + lds_words(10) + lds_pad(e)) = r;
-  __syncthreads();
-  if (W < 2) {  // stages 13..4 of the special-prime limb's inverse transform on this block, one wavefront per component
-    double *buf = dyn + W * lds_words(10);
-    double *__restrict__ dst = tsp_half + (ct * 2 + W) * (size_t)c.ps + base;
-    auto ld = [&](int, int i) { return buf[lds_pad(i)]; };
-    auto st = [&](int, int i, double v) { dst[i] = v; };
-    ntt_inv_block_a<10, FpArith, decltype(ld), decltype(st), true>(buf, ld, st, t, m, 4, blk, lane, litw);
-  }
-}
-
-static bool launch_split4_special(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const u64 *key, double *tsp_half) {
-  if (nl < 1 || nl > 4) return false;
-  const dim3 grid((unsigned)(cc * 16)), block(512);
-  const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8 + 2 * 1024 * 16;
-  switch (nl) {
-    case 1: hipLaunchKernelGGL(k_split4_special_fp<1>, grid, block, lds, st, c->dc, part, key, tsp_half); break;
-    case 2: hipLaunchKernelGGL(k_split4_special_fp<2>, grid, block, lds, st, c->dc, part, key, tsp_half); break;
-    case 3: hipLaunchKernelGGL(k_split4_special_fp<3>, grid, block, lds, st, c->dc, part, key, tsp_half); break;
-    default: hipLaunchKernelGGL(k_split4_special_fp<4>, grid, block, lds, st, c->dc, part, key, tsp_half); break;
-  }
-  return true;
-}
-
-
-// (A persistent form of k_split4_main_fp -- one workgroup per (prime, block) looping over ciphertexts, key words kept in
-// registers, the next ciphertext's operands requested before the current one is transformed -- was built and measured this
-// round: 351 k mul+relin/s with explicit prefetch at one workgroup per CU (217 VGPRs), 301 k/s at two per CU (128 VGPRs, 18
-// spilled), against 380 k/s for the per-item grid below: the hardware's workgroup turnover hides more than eight resident
-// wavefronts with a hand-rolled pipeline do.  Removed again)
-
 // K2a..K2c on one chunk (the half-done decomposition limbs are in s.dec)
 template <int MODE, bool GAL>
 static void launch_split3(hipStream_t st, abc_hip_ctx *c, const FusedScratch &s, size_t cc, int nl, const u64 *opa, const u64 *opb,
                           size_t opa_stride, size_t opb_stride, int add_c1, const u64 *key, u64 *out, u32 gelt, int pack) {
-  // (k_split4_special_fp, the LDS-table twin of the special-prime workgroups, measured 9 % slower than this: two tables to
-  // fill for four transforms; kept behind ABC_HIP_SPLIT4_SPECIAL=1 for A/B)
-  if (!c->sw.split4_special || !launch_split4_special(st, c, cc, nl, (const double *)s.dec, key, (double *)s.tsp))
-    launch_split2_tailmac<MODE, GAL>(st, c, cc, nl, (const double *)s.dec, opa, opb, opa_stride, opb_stride, add_c1, key, s.ksacc,
-                                     (double *)s.tsp, gelt, 1);
+  launch_split_special(st, c, cc, nl, (const double *)s.dec, key, (double *)s.tsp);
   hipLaunchKernelGGL(k_split3_pass_fp<14>, dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, (const double *)s.tsp, (double *)s.ksacc,
                      nl, pack);
   // (measured at nl = 5 / 6 / 7, every prime below 2^50: +9.5 / -5 / -14 % against k_split3_main_fp: above five limbs the prefetched
@@ -1517,7 +1112,7 @@ static void launch_split3(hipStream_t st, abc_hip_ctx *c, const FusedScratch &s,
 
 // packed half-done limbs (abc_ntt.hpp): only the sequence whose consumer is k_split4_main_fp reads them
 static inline int pack_half_done(const abc_hip_ctx *c, int nl) {
-  return (!c->sw.no_pack && !c->sw.no_split3 && !c->sw.no_split4 && nl >= 1 && nl <= 5) ? 1 : 0;
+  return (!c->sw.no_pack && !c->sw.no_split4 && nl >= 1 && nl <= 5) ? 1 : 0;
 }
 static inline bool all_fp(const abc_hip_ctx *c) {  // fp64 transforms: every key prime below 2^50
   bool fp = c->use_fp;
@@ -1534,8 +1129,7 @@ static inline bool needs_guard(const abc_hip_ctx *c) {  // unguarded butterflies
 template <int LB>
 static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s, const u64 *coef, size_t coef_stride, const u64 *ntt,
                            size_t ntt_stride, const u64 *key, const u64 *addend, size_t addend_stride, bool add_c1, u64 *out, int nl,
-                           size_t cc, int dec_ready = 0 /* 1: dec holds finished limbs, 2: half-done limbs (split) */,
-                           u32 gelt = 0 /* split CKKS path: Galois element folded into the operand / addend reads */) {
+                           size_t cc, int dec_ready = 0 /* 1: dec already holds the transformed decomposition limbs */) {
   const size_t N = (size_t)1 << LB;
   const dim3 block((1 << LB) / 16);
   const bool ckks = (c->scheme == 2);
@@ -1545,24 +1139,12 @@ static int keyswitch_stage(abc_hip_ctx *c, hipStream_t st, const FusedScratch &s
   if (all_fp(c)) {
     if (!dec_ready)
       hipLaunchKernelGGL(k_fused_ks_decomp_ntt_fp<LB>, dim3(g2a), block, 0, st, c->dc, coef, coef_stride, s.dec, nl, ckks ? 1 : 0);
-    // cooperative form: nl wavefronts and 8.5 max(nl, 2) KiB of LDS per workgroup
-    if (dec_ready == 2 && nl <= 12 && !c->sw.tailmac_serial)
-      hipLaunchKernelGGL((gelt ? k_fused_tailmac_coop_fp<true> : k_fused_tailmac_coop_fp<false>), dim3((unsigned)(cc * (nl + 1) * 16)),
-                         dim3(64 * nl),
-                         (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8, st, c->dc, (const double *)s.dec,
-                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, gelt);
-    else if (dec_ready == 2)
-      hipLaunchKernelGGL((gelt ? k_fused_tailmac_fp<true> : k_fused_tailmac_fp<false>), dim3((unsigned)(cc * (nl + 1) * 16)), dim3(64), 0,
-                         st, c->dc, (const double *)s.dec,
-                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, gelt);
-    else
-      hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
-                         ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
+    hipLaunchKernelGGL(k_fused_ks_mac, dim3(stream_grid(cc * (nl + 1) * (N / 2), 256)), dim3(256), 0, st, c->dc, s.dec,
+                       ckks ? ntt : (const u64 *)nullptr, ntt_stride, key, s.ksacc, s.tsp, nl, cc);
     hipLaunchKernelGGL(k_fused_ks_special_intt_fp<LB>, dim3((unsigned)(cc * 2)), block, 0, st, c->dc, s.tsp, s.tlast);
     if (ckks)
-      hipLaunchKernelGGL((gelt ? k_fused_ks_moddown_fp<LB, true> : k_fused_ks_moddown_fp<LB, false>), dim3(g3), block, 0, st, c->dc,
-                         s.ksacc, s.tlast, addend, addend_stride,
-                         add_c1 ? 1 : 0, out, nl, (int)(cc * 2), gelt);
+      hipLaunchKernelGGL((k_fused_ks_moddown_fp<LB, false>), dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
+                         add_c1 ? 1 : 0, out, nl, (int)(cc * 2), 0u);
     else
       hipLaunchKernelGGL(k_fused_ks_moddown_bfv_fp<LB>, dim3(g3), block, 0, st, c->dc, s.ksacc, s.tlast, addend, addend_stride,
                          add_c1 ? 1 : 0, out, nl);
@@ -1695,9 +1277,10 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
   if (LB == 14 && !all_fp(c) && isplit_applies(c, nl))
     return run_isplit(c, 0, a, b, 2 * (size_t)nl * N, 2 * (size_t)nl * N, false, c->d_relin, out, nl, count, 0u);
   const ChunkPlan p = plan_chunks(c, nl, count);
-  // scratch limbs of the split2+ kernels are c->dc.ps words apart (N plus an optional pad, see abc_hip_ctx_create)
-  const bool use2 = LB == 14 && all_fp(c) && !c->sw.no_tensor_decomp && !c->sw.no_split && !c->sw.no_split2 && nl <= 12;
-  const size_t SN = use2 ? (size_t)c->dc.ps : N;
+  // the split sequence (N = 2^14, every key prime below 2^50); its scratch limbs are c->dc.ps words apart (N plus an optional
+  // pad, see abc_hip_ctx_create).  Otherwise: the LDS-resident kernels (smaller rings, ABC_HIP_NO_SPLIT, wider primes)
+  const bool split = LB == 14 && all_fp(c) && !c->sw.no_split && nl <= 12;
+  const size_t SN = split ? (size_t)c->dc.ps : N;
   const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
   LaneScope scope(c, p.lanes);
@@ -1709,48 +1292,30 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
     const int l = (p.lanes > 1) ? turn % p.lanes : 0;
     hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
     const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, SN);
-    const bool fuse_decomp = all_fp(c) && !c->sw.no_tensor_decomp;
-    bool split = false;
-    if constexpr (LB == 14) split = fuse_decomp && !c->sw.no_split;
     if constexpr (LB == 14) {
-      if (split && !c->sw.no_split2 && nl <= 12) {  // second-generation split kernels: three launches, 84 limb transfers
+      if (split) {
         // few ciphertexts in flight: the 139 KiB workgroups of the tensor kernel would leave most CUs idle for its whole
         // duration; the block-wise inverse tails + register cross pass of abc_kernels_gsplit.hip spread over the chip instead
-        const bool lean = !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= c->sw.lean_limit;  // measured at nl = 4: +5 % at 16 pairs, even at 32, -5 % at 48
+        const bool lean = !c->sw.no_lean_front && cc * nl <= c->sw.lean_limit;  // measured at nl = 4: +5 % at 16 pairs, even at 32, -5 % at 48
         const int pack = pack_half_done(c, nl);
         if (lean)
           gsplit_front14(st, c, cc, nl, 0, a + off * ctw, b + off * ctw, 0, (double *)s.coef, (double *)s.dec, 0u, pack);
         else
           hipLaunchKernelGGL(k_split2_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
                              b + off * ctw, (double *)s.dec, nl, pack);
-        if (!c->sw.no_split3) {
-          launch_split3<0, false>(st, c, s, cc, nl, a + off * ctw, b + off * ctw, 0, 0, 0, c->d_relin, out + off * ctw, 0u, pack);
-          ABC_HIP_CHECK(hipGetLastError());
-          continue;
-        }
-        launch_split2_tailmac<0, false>(st, c, cc, nl, (const double *)s.dec, a + off * ctw, b + off * ctw, 0, 0, 0, c->d_relin,
-                                        s.ksacc, (double *)s.tsp, 0u);
-        hipLaunchKernelGGL(k_split2_moddown_fp<LB>, dim3((unsigned)(cc * 2 * nl)), dim3((1 << LB) / 16), 0, st, c->dc, s.ksacc,
-                           (const double *)s.tsp, out + off * ctw, nl, (int)(cc * 2));
+        launch_split3<0, false>(st, c, s, cc, nl, a + off * ctw, b + off * ctw, 0, 0, 0, c->d_relin, out + off * ctw, 0u, pack);
         ABC_HIP_CHECK(hipGetLastError());
         continue;
       }
-      if (split)
-        hipLaunchKernelGGL(k_fused_tensor_pass0_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
-                           b + off * ctw, s.c01, s.ntt, (double *)s.dec, nl);
     }
-    if (split) {
-    } else if (fuse_decomp)
+    if (all_fp(c))  // tensor product, inverse transform and the forward transforms of the decomposition in one LDS-resident kernel
       hipLaunchKernelGGL(k_fused_tensor_decomp_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
                          b + off * ctw, s.c01, s.ntt, s.dec, nl);
-    else if (all_fp(c))
-      hipLaunchKernelGGL(k_fused_tensor_intt_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
-                         b + off * ctw, s.c01, s.coef, s.ntt, nl);
     else
       hipLaunchKernelGGL(k_fused_tensor_intt<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, a + off * ctw,
                          b + off * ctw, s.c01, s.coef, s.ntt, nl);
     if (keyswitch_stage<LB>(c, st, s, s.coef, (size_t)nl * N, s.ntt, (size_t)nl * N, c->d_relin, s.c01, ctw, true, out + off * ctw,
-                            nl, cc, split ? 2 : (fuse_decomp ? 1 : 0)))
+                            nl, cc, all_fp(c) ? 1 : 0))
       return 1;
   }
   return scope.join();
@@ -1791,9 +1356,11 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
   if (LB == 14 && ckks && !all_fp(c) && isplit_applies(c, nl))
     return run_isplit(c, 1, target, addend, target_stride, addend_stride, add_c1, key, out, nl, count, gelt);
   const ChunkPlan p = plan_chunks(c, nl, count);
-  const bool use2 = LB == 14 && ckks && all_fp(c) && !c->sw.no_split && !c->sw.no_split2 && nl <= 12;
-  const bool useb = LB == 14 && !ckks && !c->sw.no_split && bsplit_applies(c, nl);  // BFV: abc_kernels_gsplit.hip, k_bsplit_tcoef + k_bsplit_finish_big
-  const size_t SN = (use2 || useb) ? (size_t)c->dc.ps : N;
+  // split sequences (N = 2^14, every key prime below 2^50): CKKS as in run_mul_relin; BFV (coefficient-form operand) the
+  // register pass + abc_kernels_gsplit.hip's k_gsplit_special<14, NL, true> / k_bsplit_tcoef / k_bsplit_finish_big
+  const bool splitc = LB == 14 && ckks && all_fp(c) && !c->sw.no_split && nl <= 12;
+  const bool splitb = LB == 14 && !ckks && !c->sw.no_split && bsplit_applies(c, nl);
+  const size_t SN = (splitc || splitb) ? (size_t)c->dc.ps : N;
   const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
   LaneScope scope(c, p.lanes);
@@ -1805,59 +1372,38 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
     hipStream_t st = (p.lanes > 1) ? c->lane[l] : c->stream;
     const FusedScratch s = carve((u64 *)c->ws + (size_t)l * p.chunk * per_ct, p.chunk, nl, SN);
     const u64 *tg = target + off * target_stride;
-    const u64 *coef = tg;
-    size_t coef_stride = target_stride;
-    bool split = false;
+    const u64 *ad = addend ? addend + off * addend_stride : nullptr;
+    u64 *o = out + off * 2 * nl * N;
     if constexpr (LB == 14) {
-      split = all_fp(c) && !c->sw.no_split;
-      const int pack = (ckks && use2) ? pack_half_done(c, nl) : 0;
-      if (split && ckks && use2 && !c->sw.no_lean_front && !c->sw.no_split3 && cc * nl <= c->sw.lean_limit)
-        gsplit_front14(st, c, cc, nl, 1, tg, nullptr, target_stride, (double *)s.coef, (double *)s.dec, gelt, pack);
-      else if (split && ckks)
-        hipLaunchKernelGGL((gelt ? k_fused_operand_pass0_fp<LB, true, true> : k_fused_operand_pass0_fp<LB, true, false>),
-                           dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, 0,
-                           gelt, (use2 ? 1 : 0) | (pack ? 2 : 0));
-      else if (split && cc * nl < c->sw.pass0_target_limit)
-        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl * (nl + 1))), dim3((1 << LB) / 16), 0, st,
-                           c->dc, tg, target_stride, (double *)s.dec, nl, 1, 0u, useb ? 1 : 0);
-      else if (split)
-        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
-                           target_stride, (double *)s.dec, nl, 0, 0u, useb ? 1 : 0);
-      if (split && useb) {  // inner product + inverse tails for every key prime, then the register-only finish
-        if (bsplit_back14(c, st, cc, nl, (const double *)s.dec, (double *)s.ksacc, key, addend ? addend + off * addend_stride : nullptr,
-                          addend_stride, add_c1 ? 1 : 0, out + off * 2 * nl * N))
-          return 1;
-        continue;
-      }
-    }
-    if constexpr (LB == 14) {
-      if (split && ckks && !c->sw.no_split2 && nl <= 12) {
-        const u64 *ad = addend ? addend + off * addend_stride : nullptr;
-        if (!c->sw.no_split3) {
-          const int pack = pack_half_done(c, nl);
-          if (gelt)
-            launch_split3<1, true>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, out + off * 2 * nl * N, gelt,
-                                   pack);
-          else
-            launch_split3<1, false>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, out + off * 2 * nl * N, 0u,
-                                    pack);
-          ABC_HIP_CHECK(hipGetLastError());
-          continue;
-        }
-        if (gelt)
-          launch_split2_tailmac<1, true>(st, c, cc, nl, (const double *)s.dec, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key,
-                                         s.ksacc, (double *)s.tsp, gelt);
+      if (splitc) {
+        const int pack = pack_half_done(c, nl);
+        if (!c->sw.no_lean_front && cc * nl <= c->sw.lean_limit)
+          gsplit_front14(st, c, cc, nl, 1, tg, nullptr, target_stride, (double *)s.coef, (double *)s.dec, gelt, pack);
         else
-          launch_split2_tailmac<1, false>(st, c, cc, nl, (const double *)s.dec, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key,
-                                          s.ksacc, (double *)s.tsp, 0u);
-        hipLaunchKernelGGL(k_split2_moddown_fp<LB>, dim3((unsigned)(cc * 2 * nl)), dim3((1 << LB) / 16), 0, st, c->dc, s.ksacc,
-                           (const double *)s.tsp, out + off * 2 * nl * N, nl, (int)(cc * 2));
+          hipLaunchKernelGGL((gelt ? k_fused_operand_pass0_fp<LB, true, true> : k_fused_operand_pass0_fp<LB, true, false>),
+                             dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, 0,
+                             gelt, 1 | (pack ? 2 : 0));
+        if (gelt)
+          launch_split3<1, true>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, o, gelt, pack);
+        else
+          launch_split3<1, false>(st, c, s, cc, nl, tg, ad, target_stride, addend_stride, add_c1 ? 1 : 0, key, o, 0u, pack);
         ABC_HIP_CHECK(hipGetLastError());
         continue;
       }
+      if (splitb) {
+        // few ciphertexts in flight: one workgroup per (ct, J, target I) instead of per (ct, J)
+        const bool per_target = cc * nl < c->sw.pass0_target_limit;
+        hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl * (per_target ? nl + 1 : 1))),
+                           dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, per_target ? 1 : 0, 0u, 1);
+        // inner product + inverse tails for every key prime, then the register-only finish
+        if (bsplit_back14(c, st, cc, nl, (const double *)s.dec, (double *)s.ksacc, key, ad, addend_stride, add_c1 ? 1 : 0, o)) return 1;
+        continue;
+      }
     }
-    if (split) {
-    } else if (ckks) {  // operand arrives in NTT form: coefficient form via one in-LDS inverse transform per limb
+    // LDS-resident kernels (smaller rings, wider primes, ABC_HIP_NO_SPLIT)
+    const u64 *coef = tg;
+    size_t coef_stride = target_stride;
+    if (ckks) {  // operand arrives in NTT form: coefficient form via one in-LDS inverse transform per limb
       if (all_fp(c))
         hipLaunchKernelGGL(k_fused_operand_intt_fp<LB>, dim3((unsigned)(cc * nl)), dim3((1 << LB) / 16), 0, st, c->dc, tg,
                            target_stride, s.coef, nl);
@@ -1867,9 +1413,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
       coef = s.coef;
       coef_stride = (size_t)nl * N;
     }
-    if (keyswitch_stage<LB>(c, st, s, coef, coef_stride, tg, target_stride, key, addend ? addend + off * addend_stride : nullptr,
-                            addend_stride, add_c1, out + off * 2 * nl * N, nl, cc, split ? 2 : 0, gelt))
-      return 1;
+    if (keyswitch_stage<LB>(c, st, s, coef, coef_stride, tg, target_stride, key, ad, addend_stride, add_c1, o, nl, cc, 0)) return 1;
   }
   return scope.join();
 }

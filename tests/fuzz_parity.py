@@ -28,7 +28,9 @@ SWITCH_SETS = [
     {"ABC_HIP_NO_MIXED": "1"},
     {"ABC_HIP_NO_ISPLIT": "1"},
     {"ABC_HIP_NO_SPLIT": "1"},
-    {"ABC_HIP_NO_SPLIT3": "1"},
+    {"ABC_HIP_NO_SPLIT4": "1"},
+    {"ABC_HIP_NO_PACK": "1"},
+    {"ABC_HIP_NO_BMUL": "1"},
     {"ABC_HIP_NO_LEAN_FRONT": "1"},
     {"ABC_HIP_NO_FUSED": "1"},
     {"ABC_HIP_NO_BSPLIT": "1"},

@@ -15,14 +15,11 @@ VARIANTS = {
     "default": {},
     "integer_transforms": {"ABC_HIP_NO_FP64": "1"},  # integer split kernels (abc_kernels_isplit.hip), unguarded
     "integer_v1": {"ABC_HIP_NO_FP64": "1", "ABC_HIP_NO_ISPLIT": "1"},  # round-1 integer sequence (LDS-resident transforms)
-    "fp64_unsplit": {"ABC_HIP_NO_SPLIT": "1"},
-    "fp64_separate_kernels": {"ABC_HIP_NO_SPLIT": "1", "ABC_HIP_NO_TENSOR_DECOMP": "1"},
+    "fp64_unsplit": {"ABC_HIP_NO_SPLIT": "1"},  # LDS-resident kernels (the sequence every ring below 2^14 takes)
     "fp64_fat_front": {"ABC_HIP_NO_LEAN_FRONT": "1"},  # the 139 KiB tensor / operand kernel even for small batches
     "fp64_unpacked": {"ABC_HIP_NO_PACK": "1"},  # half-done limbs as raw doubles (default: 5 / 6 bytes for primes <= 40 / 48 bits)
     "fp64_unpacked_fat_front": {"ABC_HIP_NO_PACK": "1", "ABC_HIP_NO_LEAN_FRONT": "1"},
-    "fp64_split_v1": {"ABC_HIP_NO_SPLIT2": "1"},  # round-1 kernels: four launches, LDS-atomic accumulators
-    "fp64_split_v2": {"ABC_HIP_NO_SPLIT3": "1"},  # three launches, LDS-resident mod-down
-    "fp64_split_serial_tail": {"ABC_HIP_TAILMAC_SERIAL": "1", "ABC_HIP_NO_SPLIT2": "1"},
+    "fp64_split3_main": {"ABC_HIP_NO_SPLIT4": "1"},  # previous generation of the last step (also what six and seven data limbs take)
     "generic": {"ABC_HIP_NO_FUSED": "1"},
     "no_galois_fusion_sync_alloc": {"ABC_HIP_NO_GALOIS_FUSION": "1", "ABC_HIP_SYNC_ALLOC": "1"},
 }
@@ -95,7 +92,7 @@ def test_ckks14_paths_bit_exact(variant, oracle14, capi, monkeypatch):
     g.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "fp64_unpacked", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
+@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "fp64_unpacked", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split3_main"])
 def test_ckks14_every_level_bit_exact(variant, oracle14, capi, monkeypatch):
     """multiply + relinearise and rotate at data levels 4, 3, 2 and 1 (the cooperative tail kernel runs nl wavefronts)"""
     o, primes, ins, want = oracle14
@@ -288,7 +285,7 @@ def test_ckks14_packed_half_done_limbs(chain, front, oracle_mod, capi, monkeypat
 # several chunks per lane: the hot call splits a batch into chunks that alternate over internal streams and reuse
 # per-lane scratch; every pair of a batch that spans chunk boundaries is checked, also with `out` aliasing `a`
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "fp64_unpacked", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split_v1", "fp64_split_v2"])
+@pytest.mark.parametrize("variant", ["default", "fp64_fat_front", "fp64_unpacked", "integer_transforms", "integer_v1", "fp64_unsplit", "fp64_split3_main"])
 def test_multi_chunk_batches_every_pair(variant, oracle14, capi, monkeypatch):
     import ctypes as C
     o, primes, ins, want = oracle14

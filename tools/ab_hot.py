@@ -2,7 +2,7 @@
 """Interleaved A/B timing of the hot call under different ABC_HIP_* path switches, in ONE process on ONE device
 (cdna_hip_programming.md rule 24): variants x rounds, median and min of the per-round rates.
 
-  python tools/ab_hot.py --variants "default;ABC_HIP_NO_SPLIT2=1;ABC_HIP_LANES=1" --op mul_relin --batch 1024
+  python tools/ab_hot.py --variants "default;ABC_HIP_NO_SPLIT4=1;ABC_HIP_LANES=1" --op mul_relin --batch 1024
 """
 import argparse
 import ctypes as C
@@ -18,7 +18,7 @@ N, L = 16384, 4
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="default;ABC_HIP_NO_SPLIT2=1")
+    ap.add_argument("--variants", default="default;ABC_HIP_NO_SPLIT4=1")
     ap.add_argument("--op", default="mul_relin", choices=["mul_relin", "rotate"])
     ap.add_argument("--bits", default="50,40,40,40,50")
     ap.add_argument("--batch", type=int, default=1024)
