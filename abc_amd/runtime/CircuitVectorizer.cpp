@@ -225,11 +225,31 @@ std::string CircuitVectorizer::vectorize(const std::string &program) {
           else ok = ok && sameShape(proto->shape, kv.second->shape);
         }
       if (!ok || !proto) { giveUp(); return; }
-      out.push_back(target + " = " + join(proto->shape) + ";");
+      const auto len = lengths.find(target);
+      if (len != lengths.end() && len->second < n) { giveUp(); return; }  // writes behind the declared end: not ours to fix
+      const bool partial = len != lengths.end() && len->second > n;
       std::vector<long> mask(n, 1), add(n, 0);
       bool outliers = false;
       for (auto &kv : bySlot)
         if (kv.second->constant) { mask[kv.first] = 0; add[kv.first] = kv.second->value; outliers = true; }
+      if (partial) {
+        // the run stops short of the vector's end: merge under a mask (one more entry than the run, so that the padding of the
+        // mask lists with their last element clears / keeps everything behind slot n-1)
+        const std::string tmp = "__vt" + std::to_string(tempCounter++) + "__";
+        std::vector<long> take(mask), keep(n + 1, 0), addp(add);
+        take.push_back(0);
+        keep[n] = 1;
+        for (int i = 0; i < n; ++i) keep[i] = 0;
+        addp.push_back(0);
+        out.push_back("secret int " + tmp + " = " + join(proto->shape) + ";");
+        out.push_back(tmp + " = " + tmp + " *** " + listOf(take) + ";");
+        if (outliers) out.push_back(tmp + " = " + tmp + " +++ " + listOf(addp) + ";");
+        out.push_back(target + " = " + target + " *** " + listOf(keep) + ";");
+        out.push_back(target + " = " + target + " +++ " + tmp + ";");
+        ++elementwiseRuns;
+        return;
+      }
+      out.push_back(target + " = " + join(proto->shape) + ";");
       if (outliers) {
         out.push_back(target + " = " + target + " *** " + listOf(mask) + ";");
         out.push_back(target + " = " + target + " +++ " + listOf(add) + ";");
@@ -245,10 +265,11 @@ std::string CircuitVectorizer::vectorize(const std::string &program) {
       const int k = (int)run.members.size();
       ok = ok && k >= 2 && *idx.begin() == 0 && *idx.rbegin() == k - 1;
       if (!ok) { giveUp(); return; }
-      const std::string tmp = "__vt" + std::to_string(tempCounter++) + "__";
-      out.push_back("secret int " + tmp + " = " + join(run.members[0]->shape) + ";");
       int pow2 = 1;
       while (pow2 < k) pow2 <<= 1;
+      if (rowSlots && pow2 > rowSlots) { giveUp(); return; }  // the rotate-and-add tree must stay inside one row
+      const std::string tmp = "__vt" + std::to_string(tempCounter++) + "__";
+      out.push_back("secret int " + tmp + " = " + join(run.members[0]->shape) + ";");
       if (pow2 != k) {  // keep slots 0..k-1, clear what the padding replicated behind them
         std::vector<long> mask(k + 1, 1);
         mask[k] = 0;

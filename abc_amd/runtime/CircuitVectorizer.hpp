@@ -15,8 +15,14 @@
 //   entry per slot (upstream's sample has one too few).  The reduced value sits in slot 0 of the accumulator.
 // A secret vector cannot be indexed at run time (RuntimeVisitor.cpp:268-298 throws, pointing at the Vectorizer), so the
 // output of this pass is what makes such programs executable at all: `CircuitRuntime::executeAst(vectorize(program))`.
+// An element-wise run is taken to cover its target: x[0..n-1] = E(i) becomes x = E, which also rewrites whatever x held behind
+// slot n-1.  Where the declared length of x is known (vectorLengths) and LONGER than the run, the rewrite is a masked merge
+// instead -- x = x *** {0,..,0,1} +++ E *** {1,..,1,0} -- so a partial update leaves the other slots alone.  A reduction over k
+// terms rotates within one row of the ciphertext: with slotsPerRow set (BFV: N/2), runs whose tree would not fit are passed
+// through unchanged.
 #pragma once
 
+#include <map>
 #include <set>
 #include <string>
 #include <vector>
@@ -24,7 +30,9 @@
 class CircuitVectorizer {
  public:
   // identifiers that name scalars (accumulators): `s = s + x[i]` is a reduction only if s is one of them
-  explicit CircuitVectorizer(std::set<std::string> scalarAccumulators = {}) : scalars(std::move(scalarAccumulators)) {}
+  explicit CircuitVectorizer(std::set<std::string> scalarAccumulators = {}, std::map<std::string, int> vectorLengths = {},
+                             int slotsPerRow = 0)
+      : scalars(std::move(scalarAccumulators)), lengths(std::move(vectorLengths)), rowSlots(slotsPerRow) {}
   // returns the transformed program; statements that match no pattern are passed through unchanged, in order
   std::string vectorize(const std::string &program);
   // number of runs rewritten by the last call (tests)
@@ -32,5 +40,7 @@ class CircuitVectorizer {
 
  private:
   std::set<std::string> scalars;
+  std::map<std::string, int> lengths;  // declared length of a vector (optional)
+  int rowSlots = 0;                    // 0: unknown
   int tempCounter = 0;
 };

@@ -105,10 +105,23 @@ void HipCiphertext::rescaleIfPossible() {
   --nl;
 }
 void HipCiphertext::checkScales(double a, double b) {
-  // after a rescale the scale is Delta^2 / q_l, a hair off Delta for a 40-bit prime next to Delta = 2^40: adding such values
-  // is what every CKKS program does (SEAL makes the user overwrite the scale); anything coarser is a real mismatch
+  // after a rescale the scale is Delta^2 / q_l, a hair off Delta for a 40-bit prime next to Delta = 2^40 (relative 1e-7 .. 1e-6
+  // for the first NTT primes below a power of two): adding such values is what every CKKS program does (SEAL makes the user
+  // overwrite the scale; here the left operand's scale stands).  Anything coarser is a real mismatch.  Written so that a NaN or
+  // a non-positive scale fails too.
   const double rel = std::fabs(a - b) / std::fmax(std::fabs(a), std::fabs(b));
-  if (rel > 1e-3) throw std::runtime_error("CKKS: scale mismatch between operands (" + std::to_string(a) + " vs " + std::to_string(b) + ")");
+  if (!(a > 0.0) || !(b > 0.0) || !(rel <= 1e-5))
+    throw std::runtime_error("CKKS: scale mismatch between operands (" + std::to_string(a) + " vs " + std::to_string(b) + ")");
+}
+// a product's scale must leave room under the modulus of its level, or the message wraps around silently (SEAL throws
+// "scale out of bounds" at the same point)
+void HipCiphertext::checkScaleFits(double scale, int level) const {
+  const auto &f = getFactory();
+  double bits = 0.0;
+  for (int j = 0; j < level; ++j) bits += std::log2((double)f.prime(j));
+  if (!std::isfinite(scale) || !(scale > 0.0) || !(std::log2(scale) < bits - 1.0))
+    throw std::runtime_error("CKKS: scale 2^" + std::to_string(std::log2(scale)) + " out of bounds for a modulus of " + std::to_string(bits) +
+                             " bits (no limb left to rescale into)");
 }
 const uint64_t *HipCiphertext::alignWith(const HipCiphertext &operand, std::shared_ptr<Buffer> &keep) {
   const auto &f = getFactory();
@@ -189,6 +202,7 @@ void HipCiphertext::multiplyInplace(const AbstractCiphertext &operand) {
   adopt(std::move(t));
   if (getFactory().isCkks()) {
     sc *= cast(operand).sc;
+    checkScaleFits(sc, nl);
     rescaleIfPossible();
   }
 }
@@ -263,6 +277,7 @@ void HipCiphertext::multiplyPlainInplace(const ICleartext &operand) {
     abcHipCheck(abc_hip_multiply_plain(getFactory().context(), in(), pl, 0, t->p, 2, nl, getFactory().batchSize()), "multiply_plain");
     adopt(std::move(t));
     sc *= ps;
+    checkScaleFits(sc, nl);
     rescaleIfPossible();
     return;
   }

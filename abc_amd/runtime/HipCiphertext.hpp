@@ -45,6 +45,7 @@ class HipCiphertext : public AbstractCiphertext {
   void dropTo(int level);                       // mod_switch down (no-op at or below `level`)
   void rescaleIfPossible();                     // divide by the last prime of the current level
   static void checkScales(double a, double b);  // additions need (nearly) equal scales
+  void checkScaleFits(double scale, int level) const;  // a product's scale must stay below the modulus of its level
   // this and operand at a common level: returns the operand's pointer (possibly a temporary held in `keep`)
   const uint64_t *alignWith(const HipCiphertext &operand, std::shared_ptr<Buffer> &keep);
 

@@ -419,6 +419,12 @@ std::unique_ptr<AbstractCiphertext> HipCiphertextFactory::loadCiphertext(std::is
     if (img.size != 2) throw std::runtime_error("loadCiphertext: only relinearised (size 2) ciphertexts travel through the plugin surface");
     if (img.ringDegree != N || img.limbs != (uint64_t)found) throw std::runtime_error("loadCiphertext: dimensions contradict parms_id");
     if (img.nttForm != ckksMode) throw std::runtime_error("loadCiphertext: unexpected representation (BFV: coefficient form, CKKS: NTT form)");
+    if (ckksMode) {  // the scale comes off the wire: finite, positive and below the modulus of its level, or every later check is moot
+      double bits = 0.0;
+      for (int j = 0; j < found; ++j) bits += std::log2((double)chain[j]);
+      if (!std::isfinite(img.scale) || !(img.scale > 0.0) || !(std::log2(img.scale) < bits))
+        throw std::runtime_error("loadCiphertext: scale out of bounds for the ciphertext's level");
+    }
     if (b == 0) {
       level = found;
       scale = ckksMode ? img.scale : 1.0;

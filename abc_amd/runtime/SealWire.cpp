@@ -156,6 +156,7 @@ void getArray(Reader &r, std::vector<uint64_t> &data, uint64_t limitWords) {
   const uint64_t count = r.get<uint64_t>();
   if (count > limitWords) throw std::runtime_error("SEAL object: array larger than the caller's limit");
   if (h.size != kHeaderBytes + 8 + 8 * count) throw std::runtime_error("SEAL object: array size field inconsistent");
+  if (r.left / 8 < count) throw std::runtime_error("SEAL object: array longer than the bytes that follow it");  // before any allocation
   data.resize(count);
   r.bytes(data.data(), count * 8);
 }
@@ -175,11 +176,18 @@ std::string zlibInflate(const char *src, size_t n, uint64_t limitBytes) {
   std::memset(&zs, 0, sizeof(zs));
   if (inflateInit(&zs) != Z_OK) throw std::runtime_error("zlib: inflateInit failed");
   zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(src));
-  zs.avail_in = (uInt)n;
+  zs.avail_in = 0;
+  size_t fed = 0;  // input goes in bounded pieces: avail_in is 32 bits wide, a body may be longer
   std::string out;
   char buf[1 << 16];
   int rc = Z_OK;
   while (rc != Z_STREAM_END) {
+    if (zs.avail_in == 0 && fed < n) {
+      const size_t piece = (n - fed < ((size_t)1 << 30)) ? n - fed : ((size_t)1 << 30);
+      zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(src + fed));
+      zs.avail_in = (uInt)piece;
+      fed += piece;
+    }
     zs.next_out = reinterpret_cast<Bytef *>(buf);
     zs.avail_out = sizeof(buf);
     rc = inflate(&zs, Z_NO_FLUSH);
@@ -192,7 +200,7 @@ std::string zlibInflate(const char *src, size_t n, uint64_t limitBytes) {
       inflateEnd(&zs);
       throw std::runtime_error("SEAL object: inflated body larger than the caller's limit");
     }
-    if (rc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0) {
+    if (rc == Z_OK && zs.avail_in == 0 && fed == n && zs.avail_out != 0) {
       inflateEnd(&zs);
       throw std::runtime_error("zlib: truncated stream");
     }

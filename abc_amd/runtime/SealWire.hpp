@@ -64,13 +64,14 @@ struct KSwitchImage {
 };
 
 // all of these throw std::runtime_error (bad magic, unsupported version or compression, truncated stream, inconsistent sizes,
-// seed-compressed object); `limitWords` bounds what a load may allocate
+// seed-compressed object); `limitWords` bounds what a load may allocate (default 2^27 words = 1 GiB: a Galois key set of
+// N = 2^15 with 15 limbs is 0.5 GiB; pass more for larger objects)
 void save(std::ostream &out, const CiphertextImage &ct, Compression mode = None);
 void save(std::ostream &out, const PlaintextImage &pt, Compression mode = None);
 void save(std::ostream &out, const KSwitchImage &keys, Compression mode = None);
-void load(std::istream &in, CiphertextImage &ct, uint64_t limitWords = (uint64_t)1 << 32);
-void load(std::istream &in, PlaintextImage &pt, uint64_t limitWords = (uint64_t)1 << 32);
-void load(std::istream &in, KSwitchImage &keys, uint64_t limitWords = (uint64_t)1 << 32);
+void load(std::istream &in, CiphertextImage &ct, uint64_t limitWords = (uint64_t)1 << 27);
+void load(std::istream &in, PlaintextImage &pt, uint64_t limitWords = (uint64_t)1 << 27);
+void load(std::istream &in, KSwitchImage &keys, uint64_t limitWords = (uint64_t)1 << 27);
 
 // BLAKE2b (RFC 7693), unkeyed, outLen <= 64
 void blake2b(void *out, size_t outLen, const void *in, size_t inLen);

@@ -32,7 +32,7 @@ static __thread size_t g_arena_size = 0, g_arena_used = 0;
 static void *orc_salloc(size_t bytes) {
   if (!g_arena) return malloc(bytes);
   size_t need = (bytes + 63) & ~(size_t)63;
-  if (g_arena_used + need > g_arena_size) return NULL; /* sized generously below: cannot happen */
+  if (g_arena_used + need > g_arena_size) return malloc(bytes); /* arena exhausted (sized from the scheme below): heap, freed by orc_sfree */
   void *p = g_arena + g_arena_used;
   g_arena_used += need;
   return p;
@@ -43,7 +43,7 @@ static void *orc_szalloc(size_t bytes) {
   return p;
 }
 static void orc_sfree(void *p) {
-  if (!g_arena) free(p);
+  if (!g_arena || (unsigned char *)p < g_arena || (unsigned char *)p >= g_arena + g_arena_size) free(p); /* arena blocks are bump-allocated */
 }
 
 void orc_scaled_plain_addsub(const orc_ctx *c, const uint64_t *plain, uint64_t *poly, int sub);
@@ -472,8 +472,14 @@ int orc_ckks_add_plain(const orc_ctx *c, const uint64_t *ct, int size, int nl, c
 /* ---------- CPU baseline timing ---------- */
 double orc_time_mul_relin(const orc_ctx *c, const uint64_t *a, const uint64_t *b, int nl, int iters, uint64_t *out2) {
   struct timespec t0, t1;
-  /* arena: every temporary of one mul+relin (< 256 limbs at any scheme / level), touched once before timing */
-  size_t bytes = (size_t)256 * c->n * 8;
+  /* arena: every temporary of one mul+relin, touched once before timing.  Nothing is freed inside the arena, so it is sized by the
+   * sum of all temporaries: CKKS ~ 3L + L(L+1)-independent key-switch buffers (about 40 limbs at L = 4); BFV adds the BEHZ
+   * operands and products in q and Bsk (about 300 limbs at L = 8, nBsk = 9 or 10) */
+  size_t L = (size_t)(nl > 0 ? nl : c->L);
+  size_t nbsk = c->behz ? (size_t)c->behz->nBsk : 0;
+  size_t limbs = 64 + 16 * L + 12 * nbsk + 2 * (L + nbsk + 1) * 4;
+  if (limbs < 256) limbs = 256;
+  size_t bytes = limbs * c->n * 8;
   unsigned char *arena = (unsigned char *)malloc(bytes);
   if (arena) {
     memset(arena, 0, bytes);

@@ -147,6 +147,31 @@ static void runAll(MiniTest &t, AbstractCiphertextFactory &f, const char *backen
     for (size_t i = 0; i < 9; ++i) EXPECT_TRUE(slot0(f, in, vec, "z", i) == x[i] + y[i]);
     EXPECT_TRUE(slot0(f, in, vec, "z", 9) == 5);
   });
+  t.run(name("partial write of a longer vector: masked merge, the other slots survive").c_str(), [&] {
+    // z has ten declared slots, the run writes three of them (one with a literal): without the declared length the rewrite would
+    // be `z = x + y` and slots 3..9 would be overwritten too
+    CircuitVectorizer v({}, {{"z", 10}});
+    const std::string prog = "z[0] = x[0] + y[0];\nz[1] = 7;\nz[2] = x[2] + y[2];\n";
+    const std::string vec = v.vectorize(prog);
+    EXPECT_TRUE(v.elementwiseRuns == 1);
+    EXPECT_TRUE(vec.find("*** {1, 0, 1, 0}") != std::string::npos);   // take mask (trailing 0: the padding clears the rest)
+    EXPECT_TRUE(vec.find("z = z *** {0, 0, 0, 1}") != std::string::npos);  // keep mask
+    const std::vector<int> z0 = {10, 20, 30, 40, 50, 60, 70, 80, 90, 100};
+    const std::string in = "secret int x = " + listOf(x) + "; secret int y = " + listOf(y) + "; secret int z = " + listOf(z0) + ";";
+    EXPECT_TRUE(slot0(f, in, vec, "z", 0) == x[0] + y[0]);
+    EXPECT_TRUE(slot0(f, in, vec, "z", 1) == 7);
+    EXPECT_TRUE(slot0(f, in, vec, "z", 2) == x[2] + y[2]);
+    for (size_t i = 3; i < 10; ++i) EXPECT_TRUE(slot0(f, in, vec, "z", i) == z0[i]);
+    // a run that covers the declared length keeps the plain rewrite
+    CircuitVectorizer full({}, {{"z", 3}});
+    EXPECT_TRUE(squash(full.vectorize("z[0] = x[0];\nz[1] = x[1];\nz[2] = x[2];\n")) == squash("z = x;"));
+    // a reduction whose tree would leave the row is passed through
+    CircuitVectorizer tight({"sum"}, {}, 4);
+    std::string red;
+    for (int i = 0; i < 8; ++i) red += "sum = sum + x[" + std::to_string(i) + "];\n";
+    tight.vectorize(red);
+    EXPECT_TRUE(tight.reductionRuns == 0);
+  });
 }
 
 int main(int argc, char **argv) {

@@ -121,3 +121,14 @@ def test_bfv_multiply_does_not_depend_on_the_auxiliary_base(oracle_mod):
             got = [alt.multiply(a, b), alt.multiply(ex, ex), alt.multiply(a, ex)]
             for w, g_ in zip(want, got):
                 assert np.array_equal(w, g_), (n, bits)
+
+
+def test_timed_mul_relin_bfv_default_ring_runs_in_its_arena(oracle_mod):
+    """orc_time_mul_relin (bench.py's cpu_baseline leg) bump-allocates every temporary of one multiply from an arena: BFV on
+    BFVDefault(16384) needs ~300 limbs of it (the arena is sized from the scheme, and falls back to the heap when short)."""
+    o = oracle_mod.Oracle.bfv_default(16384)
+    o.keygen(5)
+    a = o.encrypt(o.encode(oracle_mod.expand_vector([3, 3, 1, 4, 5, 9], o.n)), 1)
+    b = o.encrypt(o.encode(oracle_mod.expand_vector([0, 1, 2, 1, 10, 21], o.n)), 2)
+    assert o.time_mul_relin(a, b, 1) > 0.0
+    assert list(o.decode(o.decrypt(o.mul_relin(a, b)))[:6]) == [0, 3, 2, 4, 50, 189]
