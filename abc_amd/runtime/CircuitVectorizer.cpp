@@ -315,3 +315,261 @@ std::string CircuitVectorizer::vectorize(const std::string &program) {
   for (const auto &line : out) text += line + "\n";
   return text;
 }
+
+
+// =====================================================================================================================
+// ExpressionBatcher
+// =====================================================================================================================
+namespace {
+
+// expression tree over leaves `name`, `name[int]`, integer literals; operators + - * (also the runtime's +++ --- ***)
+struct Expr {
+  enum Kind { Leaf, Lit, Bin } kind = Leaf;
+  std::string name;   // Leaf: identifier; Bin: operator as written
+  int index = -1;     // Leaf: element index, -1 for a scalar
+  long value = 0;     // Lit
+  std::vector<Expr> kids;
+};
+
+struct ExprParser {
+  const std::vector<Tok> &t;
+  size_t i = 0;
+  bool ok = true;
+  explicit ExprParser(const std::vector<Tok> &toks) : t(toks) {}
+  bool at(const char *p) const { return i < t.size() && isP(t[i], p); }
+  Expr primary() {
+    Expr e;
+    if (i >= t.size()) { ok = false; return e; }
+    if (at("(")) {
+      ++i;
+      e = sum();
+      if (!at(")")) ok = false; else ++i;
+      return e;
+    }
+    if (t[i].kind == Tok::Int) { e.kind = Expr::Lit; e.value = std::stol(t[i].text); ++i; return e; }
+    if (t[i].kind == Tok::Ident) {
+      e.kind = Expr::Leaf; e.name = t[i].text; ++i;
+      if (at("[")) {
+        if (i + 2 >= t.size() || t[i + 1].kind != Tok::Int || !isP(t[i + 2], "]")) { ok = false; return e; }
+        e.index = std::stoi(t[i + 1].text);
+        i += 3;
+      }
+      if (at("(")) ok = false;  // calls are not ours
+      return e;
+    }
+    ok = false;
+    return e;
+  }
+  Expr product() {
+    Expr l = primary();
+    while (ok && (at("*") || at("***"))) {
+      Expr b; b.kind = Expr::Bin; b.name = "*"; ++i;
+      b.kids.push_back(l); b.kids.push_back(primary());
+      l = b;
+    }
+    return l;
+  }
+  Expr sum() {
+    Expr l = product();
+    while (ok && (at("+") || at("+++") || at("-") || at("---"))) {
+      Expr b; b.kind = Expr::Bin; b.name = (at("+") || at("+++")) ? "+" : "-"; ++i;
+      b.kids.push_back(l); b.kids.push_back(product());
+      l = b;
+    }
+    return l;
+  }
+};
+
+bool sameTreeShape(const Expr &a, const Expr &b) {  // operators and literals equal, leaves free
+  if (a.kind != b.kind) return false;
+  if (a.kind == Expr::Lit) return a.value == b.value;
+  if (a.kind == Expr::Leaf) return true;
+  if (a.name != b.name || a.kids.size() != b.kids.size()) return false;
+  for (size_t k = 0; k < a.kids.size(); ++k)
+    if (!sameTreeShape(a.kids[k], b.kids[k])) return false;
+  return true;
+}
+void leavesOf(const Expr &e, std::vector<const Expr *> &out) {
+  if (e.kind == Expr::Leaf) out.push_back(&e);
+  for (const auto &k : e.kids) leavesOf(k, out);
+}
+void flattenSum(const Expr &e, std::vector<const Expr *> &terms, bool &plusOnly) {
+  if (e.kind == Expr::Bin && (e.name == "+" || e.name == "-")) {
+    if (e.name == "-") plusOnly = false;
+    flattenSum(e.kids[0], terms, plusOnly);
+    flattenSum(e.kids[1], terms, plusOnly);
+  } else {
+    terms.push_back(&e);
+  }
+}
+// the tree with its leaves replaced, in order, by the given names
+std::string render(const Expr &e, const std::vector<std::string> &names, size_t &next, bool top = true) {
+  if (e.kind == Expr::Lit) return std::to_string(e.value);
+  if (e.kind == Expr::Leaf) return names[next++];
+  const std::string l = render(e.kids[0], names, next, false), r = render(e.kids[1], names, next, false);
+  const std::string body = l + " " + e.name + " " + r;
+  return top ? body : "(" + body + ")";
+}
+std::string leafText(const Expr &l) { return l.index < 0 ? l.name : l.name + "[" + std::to_string(l.index) + "]"; }
+
+struct Assign {
+  std::string target;
+  int slot = -1;  // x[slot] = ..., -1: x = ...
+  Expr rhs;
+};
+bool parseAssign(const std::vector<Tok> &t, Assign &a) {
+  if (t.size() < 3 || t[0].kind != Tok::Ident) return false;
+  size_t eq = 1;
+  a.target = t[0].text;
+  if (isP(t[1], "[")) {
+    if (t.size() < 6 || t[2].kind != Tok::Int || !isP(t[3], "]")) return false;
+    a.slot = std::stoi(t[2].text);
+    eq = 4;
+  }
+  if (!isP(t[eq], "=")) return false;
+  const std::vector<Tok> rhs(t.begin() + eq + 1, t.end());
+  ExprParser p(rhs);
+  a.rhs = p.sum();
+  return p.ok && p.i == rhs.size();
+}
+
+}  // namespace
+
+ExpressionBatcher::Result ExpressionBatcher::batch(const std::string &program) {
+  Result res;
+  // top-level statements (no blocks: anything with braces is not ours)
+  std::vector<std::vector<Tok>> stmts(1);
+  for (const Tok &t : lex(program)) {
+    if (isP(t, "{") || isP(t, "}")) return res;
+    if (isP(t, ";")) { if (!stmts.back().empty()) stmts.emplace_back(); continue; }
+    stmts.back().push_back(t);
+  }
+  if (stmts.back().empty()) stmts.pop_back();
+  std::vector<Assign> as(stmts.size());
+  for (size_t k = 0; k < stmts.size(); ++k)
+    if (!parseAssign(stmts[k], as[k])) return res;
+  if (as.empty()) return res;
+  auto tmp = [&] { return "__eb" + std::to_string(tempCounter++) + "__"; };
+  auto listOfL = [](const std::vector<long> &v) { return listOf(v); };
+
+  // ---- 1. matrix-vector product ----
+  {
+    const int R = (int)as.size();
+    bool ok = R >= 2;
+    int C = 0;
+    std::string A, B;
+    for (int k = 0; ok && k < R; ++k) {
+      ok = as[k].target == as[0].target && as[k].slot == k;
+      std::vector<const Expr *> terms;
+      bool plusOnly = true;
+      if (ok) flattenSum(as[k].rhs, terms, plusOnly);
+      ok = ok && plusOnly && (k == 0 ? terms.size() >= 2 : (int)terms.size() == C);
+      if (k == 0) C = (int)terms.size();
+      for (int j = 0; ok && j < C; ++j) {
+        const Expr &t = *terms[j];
+        ok = t.kind == Expr::Bin && t.name == "*" && t.kids[0].kind == Expr::Leaf && t.kids[1].kind == Expr::Leaf &&
+             t.kids[0].index >= 0 && t.kids[1].index >= 0;
+        if (!ok) break;
+        const Expr *a = &t.kids[0], *b = &t.kids[1];
+        if (!(a->index == k * C + j && b->index == j)) std::swap(a, b);  // either operand order
+        ok = a->index == k * C + j && b->index == j;
+        if (k == 0 && j == 0) { A = a->name; B = b->name; }
+        ok = ok && a->name == A && b->name == B && A != B && A != as[0].target && B != as[0].target;
+      }
+    }
+    if (ok) {
+      const std::string c = as[0].target, bm = tmp(), bb = tmp(), t = tmp(), s = tmp();
+      std::vector<long> maskC(C + 1, 1);
+      maskC[C] = 0;
+      std::string p;
+      p += "secret int " + bm + " = " + B + " *** " + listOfL(maskC) + ";\n";  // the runtime pads with the last value: clear it
+      p += "secret int " + bb + " = " + bm + ";\n";
+      for (int r = 1; r < R; ++r) p += bb + " = " + bb + " +++ rotate(" + bm + ", " + std::to_string(-r * C) + ");\n";
+      p += "secret int " + t + " = " + A + " *** " + bb + ";\n";  // slot kC + j = a[kC + j] b[j]
+      p += "secret int " + s + " = " + t + ";\n";
+      for (int d = 1; d < C; ++d) p += s + " = " + s + " +++ rotate(" + t + ", " + std::to_string(d) + ");\n";  // slot kC = c_k
+      for (int k = 0; k < R; ++k) {  // compaction: slot kC -> slot k
+        std::vector<long> unit(k * C + 2, 0);
+        unit[k * C] = 1;
+        const std::string u = tmp();
+        p += "secret int " + u + " = " + s + " *** " + listOfL(unit) + ";\n";
+        if (k == 0) p += c + " = " + u + ";\n";
+        else p += c + " = " + c + " +++ rotate(" + u + ", " + std::to_string(k * (C - 1)) + ");\n";
+      }
+      res.program = p;
+      res.aux = c + " = {" + c + "[0], .., " + c + "[" + std::to_string(R - 1) + "]};\n";
+      res.batched = true;
+      res.rule = "matrix-vector";
+      return res;
+    }
+  }
+
+  // ---- 2. same-shaped statements over scalar leaves: one input vector per leaf position ----
+  if (as.size() >= 2) {
+    bool ok = true;
+    std::vector<std::vector<const Expr *>> leaves(as.size());
+    for (size_t k = 0; ok && k < as.size(); ++k) {
+      ok = as[k].target == as[0].target && as[k].slot == (int)k && sameTreeShape(as[0].rhs, as[k].rhs);
+      if (ok) leavesOf(as[k].rhs, leaves[k]);
+      ok = ok && !leaves[k].empty() && leaves[k].size() == leaves[0].size();
+      for (const Expr *l : leaves[k]) ok = ok && l->index < 0;  // scalars only: indexed leaves are the CircuitVectorizer's patterns
+    }
+    if (ok) {
+      std::vector<std::string> names;
+      for (size_t pos = 0; pos < leaves[0].size(); ++pos) {
+        const std::string in = "__input" + std::to_string(pos) + "__";
+        names.push_back(in);
+        res.aux += in + " = {";
+        for (size_t k = 0; k < as.size(); ++k) res.aux += (k ? ", " : "") + leafText(*leaves[k][pos]);
+        res.aux += "};\n";
+      }
+      size_t next = 0;
+      res.program = as[0].target + " = " + render(as[0].rhs, names, next) + ";\n";
+      res.batched = true;
+      res.rule = "statements";
+      return res;
+    }
+  }
+
+  // ---- 3. one expression = a sum of same-shaped terms ----
+  if (as.size() == 1 && as[0].slot < 0) {
+    std::vector<const Expr *> terms;
+    bool plusOnly = true;
+    flattenSum(as[0].rhs, terms, plusOnly);
+    bool ok = plusOnly && terms.size() >= 2;
+    std::vector<std::vector<const Expr *>> leaves(terms.size());
+    for (size_t j = 0; ok && j < terms.size(); ++j) {
+      ok = sameTreeShape(*terms[0], *terms[j]);
+      if (ok) leavesOf(*terms[j], leaves[j]);
+      ok = ok && !leaves[j].empty() && leaves[j].size() == leaves[0].size();
+      for (const Expr *l : leaves[j]) ok = ok && l->index < 0;
+    }
+    if (ok) {
+      const int k = (int)terms.size();
+      std::vector<std::string> names;
+      for (size_t pos = 0; pos < leaves[0].size(); ++pos) {
+        const std::string in = "__input" + std::to_string(pos) + "__";
+        names.push_back(in);
+        res.aux += in + " = {";
+        for (int j = 0; j < k; ++j) res.aux += (j ? ", " : "") + leafText(*leaves[j][pos]);
+        res.aux += "};\n";
+      }
+      res.aux += as[0].target + " = __input0__[0];\n";
+      size_t next = 0;
+      std::string p = "__input0__ = " + render(*terms[0], names, next) + ";\n";
+      int pow2 = 1;
+      while (pow2 < k) pow2 <<= 1;
+      if (pow2 != k) {  // clear what the padding replicated behind the k terms
+        std::vector<long> mask(k + 1, 1);
+        mask[k] = 0;
+        p += "__input0__ = __input0__ *** " + listOfL(mask) + ";\n";
+      }
+      for (int sft = pow2 / 2; sft >= 1; sft /= 2) p += "__input0__ = __input0__ + rotate(__input0__, " + std::to_string(sft) + ");\n";
+      res.program = p;
+      res.batched = true;
+      res.rule = "sum-of-terms";
+      return res;
+    }
+  }
+  return res;
+}

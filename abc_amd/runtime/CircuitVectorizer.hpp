@@ -44,3 +44,34 @@ class CircuitVectorizer {
   int rowSlots = 0;                    // 0: unknown
   int tempCounter = 0;
 };
+
+// ExpressionBatcher -- batching of expression TREES, the part of the front end that ref:src/visitor/ExpressionBatcher.cpp:141-221,
+// 272-347 stops short of (it computes batchability and never emits) and whose expectations are the DISABLED cases
+// ref:test/visitor/ExpressionBatcherTest.cpp:8-41 and ref:test/visitor/VectorizerTest.cpp:370-526.  Three rewrites, tried in order:
+//   1. matrix-vector product (VectorizerTest.cpp:370-433):  c[k] = a[kC] b[0] + ... + a[kC + C-1] b[C-1],  k = 0..R-1  (a row
+//      major, "merged" indices as upstream's comment has them)  ->  b masked to C slots and replicated R times, ONE slot-wise
+//      product, an in-group rotate-and-add, and a masked compaction that leaves c = {c_0, .., c_{R-1}}.  Upstream's expected
+//      text is the first of these steps only, written as R products (c = a*b; c = c + a*rotate(b,-3); ...): it yields the R C
+//      products, never sums them, and assumes b is zero behind its data whereas the runtime pads with the LAST value.
+//   2. same-shaped statements (batchableExpressionVectorizable, :484-526):  x[k] = E_k  with one tree shape over scalar leaves
+//      ->  one input vector per leaf position ({a,e,i,m}, {b,f,j,n}, ...) and ONE slot-wise evaluation x = E(inputs).  (Upstream's
+//      "ideal" text packs all sixteen leaves into one ciphertext and multiplies it with rotations of itself by 4 and 2 -- which
+//      does not pair a with b; its own comment says the pass would not produce it.)
+//   3. one expression that is a sum of same-shaped terms (batchableExpression, ExpressionBatcherTest.cpp:8-41 = VectorizerTest.cpp:
+//      434-480):  x = (a*b) + (c*d)  ->  inputs {a,c}, {b,d}; __input0__ = __input0__ * __input1__; a rotate-and-add tree; the
+//      result in slot 0 -- upstream's expected text, token for token.
+// `aux` is what upstream calls the auxiliary information: how the CALLER must pack the scalar inputs (`__inputN__ = {a, c};`)
+// and where results come out (`x = __input0__[0];`); `program` is the batched circuit in the runtime's input language
+// (rotate() takes a variable, so sub-expressions that are rotated get named temporaries).
+class ExpressionBatcher {
+ public:
+  struct Result {
+    std::string aux, program;
+    bool batched = false;
+    std::string rule;  // "matrix-vector", "statements", "sum-of-terms"
+  };
+  Result batch(const std::string &program);
+
+ private:
+  int tempCounter = 0;
+};

@@ -86,7 +86,7 @@ static std::string squash(const std::string &s) {  // whitespace-insensitive com
     if (!std::isspace((unsigned char)ch)) r += ch;
   return r;
 }
-static std::string listOf(const std::vector<int> &v) {
+static std::string listOf(const std::vector<int> &v) {  // also takes a braced list
   std::ostringstream os;
   os << "{";
   for (size_t i = 0; i < v.size(); ++i) os << (i ? ", " : "") << v[i];
@@ -171,6 +171,52 @@ static void runAll(MiniTest &t, AbstractCiphertextFactory &f, const char *backen
     for (int i = 0; i < 8; ++i) red += "sum = sum + x[" + std::to_string(i) + "];\n";
     tight.vectorize(red);
     EXPECT_TRUE(tight.reductionRuns == 0);
+  });
+  // ---- ExpressionBatcher: expression trees (ExpressionBatcherTest.cpp:8-41, VectorizerTest.cpp:370-526), executed ----
+  t.run(name("batchableExpression: x = (a*b) + (c*d), upstream's expected text, executed").c_str(), [&] {
+    ExpressionBatcher eb;
+    const auto r = eb.batch("x = (a*b) + (c*d);");
+    EXPECT_TRUE(r.batched && r.rule == "sum-of-terms");
+    EXPECT_TRUE(squash(r.program) == squash("__input0__ = __input0__ * __input1__; __input0__ = __input0__ + rotate(__input0__,1);"));
+    EXPECT_TRUE(squash(r.aux) == squash("__input0__ = {a, c}; __input1__ = {b, d}; x = __input0__[0];"));
+    const int a = 7, b = 6, c = 5, d = 4;
+    const std::string in = "secret int __input0__ = " + listOf({a, c}) + "; secret int __input1__ = " + listOf({b, d}) + ";";
+    EXPECT_TRUE(slot0(f, in, r.program, "__input0__") == a * b + c * d);
+    // three terms: masked to three slots, tree over four
+    ExpressionBatcher eb3;
+    const auto r3 = eb3.batch("x = (a*b) + (c*d) + (e*g);");
+    EXPECT_TRUE(r3.batched && r3.program.find("*** {1, 1, 1, 0}") != std::string::npos && r3.program.find("rotate(__input0__, 2)") != std::string::npos);
+    const std::string in3 = "secret int __input0__ = " + listOf({7, 5, 3}) + "; secret int __input1__ = " + listOf({6, 4, 2}) + ";";
+    EXPECT_TRUE(slot0(f, in3, r3.program, "__input0__") == 42 + 20 + 6);
+  });
+  t.run(name("batchableExpressionVectorizable: four same-shaped statements -> one slot-wise evaluation").c_str(), [&] {
+    ExpressionBatcher eb;
+    const auto r = eb.batch("x[0] = (a*b) + (c*d);\nx[1] = (e*f) + (g*h);\nx[2] = (i*j) + (k*l);\nx[3] = (m*n) + (o*p);\n");
+    EXPECT_TRUE(r.batched && r.rule == "statements");
+    EXPECT_TRUE(squash(r.aux) == squash("__input0__ = {a, e, i, m}; __input1__ = {b, f, j, n}; __input2__ = {c, g, k, o}; __input3__ = {d, h, l, p};"));
+    EXPECT_TRUE(squash(r.program) == squash("x = (__input0__ * __input1__) + (__input2__ * __input3__);"));
+    const std::vector<int> i0 = {1, 2, 3, 4}, i1 = {5, 6, 7, 8}, i2 = {9, 8, 7, 6}, i3 = {2, 3, 4, 5};
+    const std::string in = "secret int __input0__ = " + listOf(i0) + "; secret int __input1__ = " + listOf(i1) + "; secret int __input2__ = " +
+                           listOf(i2) + "; secret int __input3__ = " + listOf(i3) + "; secret int x = {0};";
+    for (size_t k = 0; k < 4; ++k) EXPECT_TRUE(slot0(f, in, r.program, "x", k) == i0[k] * i1[k] + i2[k] * i3[k]);
+  });
+  t.run(name("matrixVectorTest: c[k] = sum_j a[3k+j] b[j], replicate / multiply / in-group sum / compaction").c_str(), [&] {
+    ExpressionBatcher eb;
+    const auto r = eb.batch("c[0] = a[0]*b[0] + a[1]*b[1] + a[2]*b[2];\nc[1] = a[3]*b[0] + a[4]*b[1] + a[5]*b[2];\n"
+                            "c[2] = a[6]*b[0] + a[7]*b[1] + a[8]*b[2];\n");
+    EXPECT_TRUE(r.batched && r.rule == "matrix-vector");
+    EXPECT_TRUE(r.program.find("rotate(__eb0__, -3)") != std::string::npos && r.program.find("rotate(__eb0__, -6)") != std::string::npos);
+    const std::vector<int> a = {1, 2, 3, 4, 5, 6, 7, 8, 9}, b = {2, 0, 5};
+    const std::string in = "secret int a = " + listOf(a) + "; secret int b = " + listOf(b) + "; secret int c = {0};";
+    for (size_t k = 0; k < 3; ++k) EXPECT_TRUE(slot0(f, in, r.program, "c", k) == a[3 * k] * b[0] + a[3 * k + 1] * b[1] + a[3 * k + 2] * b[2]);
+    EXPECT_TRUE(slot0(f, in, r.program, "c", 3) == 0);  // nothing behind the result
+    // upstream's expected text (its first step: the nine products) on a b that is cleared behind its data gives the same products
+    const std::string up = "secret int bm = b *** {1, 1, 1, 0}; secret int r1 = rotate(bm, -3); secret int r2 = rotate(bm, -6);"
+                           "c = a * bm; c = c + a * r1; c = c + a * r2;";
+    for (size_t i = 0; i < 9; ++i) EXPECT_TRUE(slot0(f, in, up, "c", i) == a[i] * b[i % 3]);
+    // statements that fit no rule are left alone
+    ExpressionBatcher none;
+    EXPECT_TRUE(!none.batch("x = a - b;").batched && !none.batch("x[0] = a[0] * b[1];\nx[1] = a[5] * b[0];\n").batched);
   });
 }
 
