@@ -259,8 +259,10 @@ int main(int argc, char **argv) {
   runAll(t, model, "cleartext slot model");
 #ifndef VECTORIZER_CPU_ONLY
   if (!(argc > 1 && std::string(argv[1]) == "cpu")) {
-    HipCiphertextFactory hipf(4096, 0, 0xABC0F4ull);
-    runAll(t, hipf, "HIP backend, BFV N=4096");
+    // N = 8192 (four 43/44-bit data limbs): the expression-tree circuits put a mask multiply behind a ct x ct product and another
+    // behind that -- more multiplicative depth than BFVDefault(4096)'s two limbs carry
+    HipCiphertextFactory hipf(8192, 0, 0xABC0F4ull);
+    runAll(t, hipf, "HIP backend, BFV N=8192");
   }
 #else
   (void)argc; (void)argv;
