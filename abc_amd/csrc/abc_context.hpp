@@ -284,7 +284,11 @@ struct LaneScope {
 };
 
 // BFV multiply (+ relinearise) in split form, N = 2^14 (abc_kernels_bmul.hip)
-bool bmul_applies(const abc_hip_ctx *c);
+bool bmul_applies(const abc_hip_ctx *c);           // multiply + relinearise in one sequence
+bool bmul_multiply_applies(const abc_hip_ctx *c);  // the multiply alone (also N = 2^15 / 2^16)
+int launch_ntt_fwd_block_part(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs);  // abc_kernels_ntt.hip
+int launch_bfv_tensor_inv_block(abc_hip_ctx *c, const u64 *a, const u64 *b, size_t ct_stride, u64 *d, const LimbMap &map, int nlm,
+                                size_t count);  // abc_kernels_bfv.hip
 int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t count, bool relin);
 // integer twins of the split kernels (abc_kernels_isplit.hip)
 bool isplit_applies(const abc_hip_ctx *c, int nl);

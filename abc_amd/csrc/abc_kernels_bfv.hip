@@ -349,7 +349,10 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_bfv_tensor_intt(DevCtx c, co
 // product limb fewer.
 template <int LB, bool FP>
 __global__ __launch_bounds__((1 << LB) / 16) void k_bfv_tensor_inv_block(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b,
-                                                                         u64 *__restrict__ d, LimbMap map, int nlm, int S0) {
+                                                                         u64 *__restrict__ d, LimbMap map, int nlm, int S0,
+                                                                         size_t ct_stride) {
+  // ct_stride: words between the operands of consecutive ciphertexts (2 nlm N where a and b are separate arrays of size-2
+  // ciphertexts; 4 nlm N where the four operand polynomials of a pair lie together: abc_kernels_bmul.hip)
   __shared__ u64 lds_raw[lds_words(LB)];
   const size_t N = (size_t)c.n, pw = (size_t)nlm * N;
   const int blk = blockIdx.x & ((1 << S0) - 1);
@@ -360,8 +363,8 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_bfv_tensor_inv_block(DevCtx 
   const int mid = map.id[limb];
   const Mod m = mod_at(c, mid);
   const size_t boff = (size_t)limb * N + ((size_t)blk << LB);
-  const u64 *__restrict__ a0 = a + ct * 2 * pw + boff, *__restrict__ a1 = a0 + pw;
-  const u64 *__restrict__ b0 = b + ct * 2 * pw + boff, *__restrict__ b1 = b0 + pw;
+  const u64 *__restrict__ a0 = a + ct * ct_stride + boff, *__restrict__ a1 = a0 + pw;
+  const u64 *__restrict__ b0 = b + ct * ct_stride + boff, *__restrict__ b1 = b0 + pw;
   u64 *__restrict__ o = d + (ct * 3 + comp) * pw + boff;
   if constexpr (FP) {
     double *lds = reinterpret_cast<double *>(lds_raw);
@@ -408,12 +411,23 @@ static int tensor_inv_big(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *d, co
   for (int j = 0; j < nlm; j++) fp = fp && fp_ok(c->h_mods[map.id[j]].bits);
   const int S0 = c->logn - 12;
   const dim3 grid((unsigned)((count * 3 * nlm) << S0)), block((1 << 12) / 16);
+  const size_t cts = 2 * (size_t)nlm * c->n;
   if (fp)
-    hipLaunchKernelGGL((k_bfv_tensor_inv_block<12, true>), grid, block, 0, c->stream, c->dc, a, b, d, map, nlm, S0);
+    hipLaunchKernelGGL((k_bfv_tensor_inv_block<12, true>), grid, block, 0, c->stream, c->dc, a, b, d, map, nlm, S0, cts);
   else
-    hipLaunchKernelGGL((k_bfv_tensor_inv_block<12, false>), grid, block, 0, c->stream, c->dc, a, b, d, map, nlm, S0);
+    hipLaunchKernelGGL((k_bfv_tensor_inv_block<12, false>), grid, block, 0, c->stream, c->dc, a, b, d, map, nlm, S0, cts);
   ABC_HIP_CHECK(hipGetLastError());
   return launch_ntt_inv_strided_part(c, d, map, nlm, count * 3 * nlm);
+}
+// the fp64 form alone, operands at a caller-given ciphertext stride, no strided pass behind it (abc_kernels_bmul.hip finishes)
+int launch_bfv_tensor_inv_block(abc_hip_ctx *c, const u64 *a, const u64 *b, size_t ct_stride, u64 *d, const LimbMap &map, int nlm,
+                                size_t count) {
+  if ((c->logn != 15 && c->logn != 16) || big_block_log() != 12) { set_error("tensor_inv_block: N = 2^15 / 2^16 only"); return 1; }
+  const int S0 = c->logn - 12;
+  const dim3 grid((unsigned)((count * 3 * nlm) << S0)), block((1 << 12) / 16);
+  hipLaunchKernelGGL((k_bfv_tensor_inv_block<12, true>), grid, block, 0, c->stream, c->dc, a, b, d, map, nlm, S0, ct_stride);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 template <int LB>
@@ -471,7 +485,7 @@ static void launch_behz_floor(abc_hip_ctx *c, const u64 *dq, const u64 *dB, u64 
 int bfv_multiply(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t count) {
   if (c->scheme != 1) { set_error("bfv_multiply on a non-BFV context"); return 1; }
   if (!count) return 0;
-  if (bmul_applies(c)) return bmul_split(c, a, b, out3, count, false);  // N = 2^14, BFVDefault shape: abc_kernels_bmul.hip
+  if (bmul_multiply_applies(c)) return bmul_split(c, a, b, out3, count, false);  // BFVDefault shape on fp64 primes: abc_kernels_bmul.hip
   const size_t N = (size_t)c->n;
   const int L = c->L, nBsk = c->nBsk, nlm = L + nBsk;
   // per ciphertext pair (words): aq,bq 2*2L ; aB,bB 2*2nBsk ; dq 3L ; dB 3nBsk

@@ -30,8 +30,6 @@ namespace abc {
 
 namespace {
 
-constexpr int kPos = 32;  // positions per workgroup of M1 / M3: 256-byte runs in HBM, 512 coefficients in LDS
-
 __device__ __forceinline__ double m_mulmod(double x, double y, double q, double qinv) {  // |x|, |y| <= q -> |result| < q
   const double h = x * y;
   const double l = __builtin_fma(x, y, -h);
@@ -68,22 +66,26 @@ __device__ __forceinline__ LaneMod lane_mod(const DevCtx &c, int mid) {
 }  // namespace
 
 // ---- M1 ----
-template <int LT, int NBT>
+// LOGN, R: ring and radix of the cross pass: the 2^R values one cross pass takes are N >> R apart (N = 2^14: R = 4 over 1024-point
+// blocks; N = 2^15 / 2^16: R = 3 / 4 over the 4096-point blocks of the big-ring transforms, abc_kernels_ntt.hip).  A workgroup
+// takes 512 coefficients: 2^R blocks x P = 512 >> R positions.
+template <int LOGN, int R, int LT, int NBT>
 __global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b, double *__restrict__ hA) {
   constexpr int L = LT, nBsk = NBT + 1, NLM = L + nBsk;
-  constexpr size_t N = (size_t)1 << 14;
-  extern __shared__ double dyn[];  // [NLM][16][kPos]
+  constexpr int NBLK = 1 << R, P = 512 >> R, LOGP = 9 - R, SH = LOGN - R, NPG = (1 << SH) / P;
+  constexpr size_t N = (size_t)1 << LOGN;
+  extern __shared__ double dyn[];  // [NLM][NBLK][P]
   const ABC_CONST_AS DevConst &k = *(const ABC_CONST_AS DevConst *)c.cst;
   const ABC_CONST_AS DevConstFp &f = *(const ABC_CONST_AS DevConstFp *)c.cstf;
-  const int pg = blockIdx.x & 31;
-  const int poly = (blockIdx.x >> 5) & 3;  // a0, a1, b0, b1
-  const size_t ct = blockIdx.x >> 7;
+  const int pg = (int)(blockIdx.x % (unsigned)NPG);
+  const int poly = (int)((blockIdx.x / (unsigned)NPG) & 3u);  // a0, a1, b0, b1
+  const size_t ct = blockIdx.x / (unsigned)(NPG * 4);
   const int tid = threadIdx.x;
   const size_t pw = (size_t)L * N;
   const u64 *__restrict__ src = (poly < 2 ? a : b) + ct * 2 * pw + (size_t)(poly & 1) * pw;
   {  // one coefficient per thread: (block kb, position p)
-    const int kb = tid >> 5, p = tid & 31;
-    const size_t x = ((size_t)kb << 10) + (size_t)(pg << 5) + p;
+    const int kb = tid >> LOGP, p = tid & (P - 1);
+    const size_t x = ((size_t)kb << SH) + (size_t)(pg * P) + p;
     u64 raw[L];
 #pragma unroll
     for (int i = 0; i < L; i++) raw[i] = src[(size_t)i * N + x];
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__re
     for (int i = 0; i < L; i++) {
       const Mod m = mod_at(c, i);
       const double v0 = fp_from_u64(raw[i]);
-      dyn[(i * 16 + kb) * kPos + p] = v0;
+      dyn[(i * NBLK + kb) * P + p] = v0;
       const double v = m_canon_d(fp_mul_lazy(v0, f.ext_q[i][0], f.ext_q[i][1], m.qd), m.qd, m.qinv);
       tmp[i] = v;
       mt += (u32)(u64)__double_as_longlong(v + 4503599627370496.0) * (u32)k.q_to_mtilde[i];  // mod 2^32 on the canonical residue
@@ -110,21 +112,20 @@ __global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__re
       for (int i = 0; i < L; i++) conv += fp_mul_lazy(tmp[i], row[2 * i], row[2 * i + 1], m.qd);
       const double v = m_canon_d(fp_mul_lazy(conv, f.inv_mtilde_mod_bsk[j][0], f.inv_mtilde_mod_bsk[j][1], m.qd), m.qd, m.qinv);
       dep = (u64)__double_as_longlong(v);
-      dyn[((L + j) * 16 + kb) * kPos + p] = v;
+      dyn[((L + j) * NBLK + kb) * P + p] = v;
     }
   }
   __syncthreads();
-  const int hi0[1] = {0};
-  for (int job = tid; job < NLM * kPos; job += 512) {  // one (limb, position) column per thread; the last limb is a second round
-    const int l = job >> 5, p = job & 31;
+  for (int job = tid; job < NLM * P; job += 512) {  // one (limb, position) column per thread; the last limb is a second round
+    const int l = job >> LOGP, p = job & (P - 1);
     const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
-    double x[16];
+    double x[NBLK];
 #pragma unroll
-    for (int kb = 0; kb < 16; kb++) x[kb] = dyn[(l * 16 + kb) * kPos + p];
-    fwd_pass<FpArith, 14, 0, 4>(x, hi0, lm.t, lm.kk, 0, 0);
-    double *__restrict__ dst = hA + ((ct * 4 + poly) * NLM + l) * N + (size_t)(pg << 5) + p;
+    for (int kb = 0; kb < NBLK; kb++) x[kb] = dyn[(l * NBLK + kb) * P + p];
+    fwd_cross<R>(x, lm.t, lm.kk);
+    double *__restrict__ dst = hA + ((ct * 4 + poly) * NLM + l) * N + (size_t)(pg * P) + p;
 #pragma unroll
-    for (int kb = 0; kb < 16; kb++) dst[(size_t)kb << 10] = x[kb];
+    for (int kb = 0; kb < NBLK; kb++) dst[(size_t)kb << SH] = x[kb];
   }
 }
 
@@ -175,41 +176,41 @@ __global__ __launch_bounds__(256) void k_bmul_mid(DevCtx c, const double *__rest
 }
 
 // ---- M3 ----
-// want3 = 1: plain multiply, all three components to out [ct][3][L][N], no key-switch pass
-template <int LT, int NBT>
+// want3 = 1: plain multiply, all three components to out [ct][3][L][N], no key-switch pass (the only form for N > 2^14, whose key
+// switch decomposes over 1024-point blocks: abc_kernels_gsplit.hip, bsplit_big)
+template <int LOGN, int R, int LT, int NBT>
 __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__restrict__ hD, u64 *__restrict__ out, double *__restrict__ part,
                                                       int want3) {
   constexpr int L = LT, nB = NBT, nBsk = NBT + 1, NLM = L + nBsk;
-  constexpr size_t N = (size_t)1 << 14;
-  extern __shared__ double dyn[];  // [NLM][16][kPos]
+  constexpr int NBLK = 1 << R, P = 512 >> R, LOGP = 9 - R, SH = LOGN - R, NPG = (1 << SH) / P;
+  constexpr size_t N = (size_t)1 << LOGN;
+  extern __shared__ double dyn[];  // [NLM][NBLK][P]
   const ABC_CONST_AS DevConstFp &f = *(const ABC_CONST_AS DevConstFp *)c.cstf;
-  const int pg = blockIdx.x & 31;
-  const int comp = (int)((blockIdx.x >> 5) % 3u);
-  const size_t ct = (size_t)((blockIdx.x >> 5) / 3u);
+  const int pg = (int)(blockIdx.x % (unsigned)NPG);
+  const int comp = (int)((blockIdx.x / (unsigned)NPG) % 3u);
+  const size_t ct = (size_t)((blockIdx.x / (unsigned)NPG) / 3u);
   const int tid = threadIdx.x;
-  const int hi0[1] = {0};
-  for (int job = tid; job < NLM * kPos; job += 512) {  // inverse cross pass + N^-1 of one (limb, position) column
-    const int l = job >> 5, p = job & 31;
+  for (int job = tid; job < NLM * P; job += 512) {  // inverse cross pass + N^-1 of one (limb, position) column
+    const int l = job >> LOGP, p = job & (P - 1);
     const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
-    const double *__restrict__ src = hD + ((ct * 3 + comp) * NLM + l) * N + (size_t)(pg << 5) + p;
-    double x[16];
+    const double *__restrict__ src = hD + ((ct * 3 + comp) * NLM + l) * N + (size_t)(pg * P) + p;
+    double x[NBLK];
 #pragma unroll
-    for (int kb = 0; kb < 16; kb++) x[kb] = src[(size_t)kb << 10];
-    FpArith::centre16(x, lm.kk);
-    inv_pass<FpArith, 14, 0, 4>(x, hi0, lm.t, lm.kk, 0, 0);
+    for (int kb = 0; kb < NBLK; kb++) x[kb] = fp_centre(src[(size_t)kb << SH], lm.kk.q, lm.kk.qinv);
+    inv_cross<R>(x, lm.t, lm.kk);
 #pragma unroll
-    for (int kb = 0; kb < 16; kb++) dyn[(l * 16 + kb) * kPos + p] = fp_mul_lazy(x[kb], lm.inv_n_c, lm.inv_n_cq, lm.kk.q);
+    for (int kb = 0; kb < NBLK; kb++) dyn[(l * NBLK + kb) * P + p] = fp_mul_lazy(x[kb], lm.inv_n_c, lm.inv_n_cq, lm.kk.q);
   }
   __syncthreads();
   {  // BEHZ steps (6)-(8) on one coefficient per thread (k_behz_floor_fp): scale by t, fast floor by q, Shenoy-Kumaresan back to q
-    const int kb = tid >> 5, p = tid & 31;
-    const size_t x = ((size_t)kb << 10) + (size_t)(pg << 5) + p;
+    const int kb = tid >> LOGP, p = tid & (P - 1);
+    const size_t x = ((size_t)kb << SH) + (size_t)(pg * P) + p;
     const Mod msk = mod_at(c, c.id_bsk + nB);
     double tq[L], fl[nBsk];
 #pragma unroll
     for (int i = 0; i < L; i++) {
       const Mod m = mod_at(c, i);
-      tq[i] = m_canon_d(fp_mul_lazy(dyn[(i * 16 + kb) * kPos + p], f.flr_q[i][0], f.flr_q[i][1], m.qd), m.qd, m.qinv);
+      tq[i] = m_canon_d(fp_mul_lazy(dyn[(i * NBLK + kb) * P + p], f.flr_q[i][0], f.flr_q[i][1], m.qd), m.qd, m.qinv);
     }
     u64 dep = (u64)__double_as_longlong(tq[L - 1]);
 #pragma unroll
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
       double conv = 0.0;
 #pragma unroll
       for (int i = 0; i < L; i++) conv += fp_mul_lazy(tq[i], row[2 * i], row[2 * i + 1], m.qd);
-      const double xb = fp_mul_lazy(dyn[((L + j) * 16 + kb) * kPos + p], f.tinvq_bsk[j][0], f.tinvq_bsk[j][1], m.qd);
+      const double xb = fp_mul_lazy(dyn[((L + j) * NBLK + kb) * P + p], f.tinvq_bsk[j][0], f.tinvq_bsk[j][1], m.qd);
       fl[j] = xb - fp_mul_lazy(conv, f.inv_q_mod_bsk[j][0], f.inv_q_mod_bsk[j][1], m.qd);
       dep = (u64)__double_as_longlong(fl[j]);
     }
@@ -251,43 +252,51 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
       } else {  // c2: canonical [0, q_i) as a double, the value the key switch's decomposition reduces modulo the other primes
         const double w = m_canon_d(v, m.qd, m.qinv);
         dep = (u64)__double_as_longlong(w);
-        dyn[(i * 16 + kb) * kPos + p] = w;
+        dyn[(i * NBLK + kb) * P + p] = w;
       }
     }
     if (to_out) return;
   }
-  __syncthreads();
-  // key switch, first step: digit J of c2 at this position group, forward cross pass modulo every key prime I (two halves of the
-  // key primes on two sets of wavefronts) -> part[ct][I][J], the layout k_gsplit_special<14, L, true> reads
-  const size_t PS = (size_t)c.ps;
-  for (int job = tid; job < L * kPos * 2; job += 512) {
-    const int p = job & 31, J = (job >> 5) % L;
-    const int half = __builtin_amdgcn_readfirstlane((job >> 5) / L);  // wave-uniform: a wavefront covers two J of one half (L even)
-    const int I0 = half ? (L + 2) / 2 : 0, I1 = half ? L + 1 : (L + 2) / 2;
-    double x[16];
+  if constexpr (LOGN == 14) {
+    __syncthreads();
+    // key switch, first step: digit J of c2 at this position group, forward cross pass modulo every key prime I (two halves of
+    // the key primes on two sets of wavefronts) -> part[ct][I][J], the layout k_gsplit_special<14, L, true> reads
+    const size_t PS = (size_t)c.ps;
+    for (int job = tid; job < L * P * 2; job += 512) {
+      const int p = job & (P - 1), J = (job >> LOGP) % L;
+      const int half = __builtin_amdgcn_readfirstlane((job >> LOGP) / L);  // wave-uniform: a wavefront covers two J of one half (L even)
+      const int I0 = half ? (L + 2) / 2 : 0, I1 = half ? L + 1 : (L + 2) / 2;
+      double x[NBLK];
 #pragma unroll
-    for (int kb = 0; kb < 16; kb++) x[kb] = dyn[(J * 16 + kb) * kPos + p];
-    for (int I = I0; I < I1; I++) {
-      const int ki = (I == L) ? c.K - 1 : I;
-      const Mod m = mod_at(c, ki);
-      const FpTable t = fp_table(c, ki);
-      const FpK kk = FpArith::consts(m);
-      double y[16];
+      for (int kb = 0; kb < NBLK; kb++) x[kb] = dyn[(J * NBLK + kb) * P + p];
+      for (int I = I0; I < I1; I++) {
+        const int ki = (I == L) ? c.K - 1 : I;
+        const Mod m = mod_at(c, ki);
+        const FpTable t = fp_table(c, ki);
+        const FpK kk = FpArith::consts(m);
+        double y[NBLK];
 #pragma unroll
-      for (int kb = 0; kb < 16; kb++) y[kb] = x[kb];
-      fwd_pass<FpArith, 14, 0, 4>(y, hi0, t, kk, 0, 0);
-      double *__restrict__ dst = part + ((ct * (L + 1) + I) * L + J) * PS + (size_t)(pg << 5) + p;
+        for (int kb = 0; kb < NBLK; kb++) y[kb] = x[kb];
+        fwd_cross<R>(y, t, kk);
+        double *__restrict__ dst = part + ((ct * (L + 1) + I) * L + J) * PS + (size_t)(pg * P) + p;
 #pragma unroll
-      for (int kb = 0; kb < 16; kb++) dst[(size_t)kb << 10] = y[kb];
+        for (int kb = 0; kb < NBLK; kb++) dst[(size_t)kb << SH] = y[kb];
+      }
     }
   }
 }
 
 // ---- host side ----
-bool bmul_applies(const abc_hip_ctx *c) {
-  return c->scheme == 1 && c->logn == 14 && c->use_fp && c->behz_fp && !c->sw.no_bmul && !c->sw.no_split && !c->sw.no_fused && c->L == 8 &&
-         c->nB == 8 && c->K == c->L + 1 &&
-         bsplit_applies(c, c->L);
+static bool bmul_shape(const abc_hip_ctx *c) {
+  return c->scheme == 1 && c->use_fp && c->behz_fp && !c->sw.no_bmul && !c->sw.no_split && !c->sw.no_fused && c->L == 8 && c->nB == 8 &&
+         c->K == c->L + 1;
+}
+// multiply + relinearise in one sequence (N = 2^14)
+bool bmul_applies(const abc_hip_ctx *c) { return c->logn == 14 && bmul_shape(c) && bsplit_applies(c, c->L); }
+// the multiply alone (size-3 product): also N = 2^15 / 2^16 over the 4096-point blocks of the big-ring transforms
+bool bmul_multiply_applies(const abc_hip_ctx *c) {
+  if (c->logn == 14) return bmul_applies(c);
+  return (c->logn == 15 || c->logn == 16) && bmul_shape(c) && !c->sw.no_gsplit && big_block_log() == 12;
 }
 
 // scratch per ciphertext pair (words): X = max(hA, part) | Y = max(hD, half + tco)
@@ -299,9 +308,51 @@ static size_t bmul_scratch_words(const abc_hip_ctx *c) {
   return X + Y;
 }
 
+// N = 2^15 / 2^16: M1, the block tails of the forward transforms (k_ntt_fwd_fp<12>), the tensor product inside the block tails of
+// the inverse ones (k_bfv_tensor_inv_block<12>), M3 -- where the generic sequence ran extend, two strided + two block forward
+// passes, two tensor / block-inverse launches, two strided inverse passes and the floor (704 limb transfers per pair; here 498)
+static int bmul_big(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_t count) {
+  const size_t N = (size_t)c->n;
+  const int L = c->L, nlm = c->L + c->nBsk;
+  const size_t per_ct = (size_t)7 * nlm * N;
+  size_t chunk = (((size_t)2 << 30) / 8) / per_ct;
+  if (c->sw.bfv_scratch_mb) chunk = (c->sw.bfv_scratch_mb << 20) / 8 / per_ct;
+  if (chunk < 1) chunk = 1;
+  if (chunk > count) chunk = count;
+  if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
+  LimbMap map{};
+  for (int j = 0; j < L; j++) map.id[j] = j;
+  for (int j = 0; j < c->nBsk; j++) map.id[L + j] = c->dc.id_bsk + j;
+  const size_t lds = (size_t)nlm * 512 * 8;
+  hipStream_t st = c->stream;
+  for (size_t off = 0; off < count; off += chunk) {
+    const size_t cc = (count - off < chunk) ? count - off : chunk;
+    double *X = (double *)c->ws, *Y = X + cc * 4 * nlm * N;
+    const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
+    u64 *po = out3 + off * 3 * L * N;
+    if (c->logn == 16)
+      hipLaunchKernelGGL((k_bmul_front<16, 4, 8, 8>), dim3((unsigned)(cc * 4 * 128)), dim3(512), lds, st, c->dc, pa, pb, X);
+    else
+      hipLaunchKernelGGL((k_bmul_front<15, 3, 8, 8>), dim3((unsigned)(cc * 4 * 64)), dim3(512), lds, st, c->dc, pa, pb, X);
+    ABC_HIP_CHECK(hipGetLastError());
+    if (launch_ntt_fwd_block_part(c, (u64 *)X, map, nlm, cc * 4 * nlm)) return 1;
+    if (launch_bfv_tensor_inv_block(c, (const u64 *)X, (const u64 *)X + 2 * (size_t)nlm * N, 4 * (size_t)nlm * N, (u64 *)Y, map, nlm, cc)) return 1;
+    if (c->logn == 16)
+      hipLaunchKernelGGL((k_bmul_back<16, 4, 8, 8>), dim3((unsigned)(cc * 3 * 128)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, 1);
+    else
+      hipLaunchKernelGGL((k_bmul_back<15, 3, 8, 8>), dim3((unsigned)(cc * 3 * 64)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, 1);
+    ABC_HIP_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
 // relin = true: out [count][2][L][N] = relinearised product; false: out [count][3][L][N] = the size-3 product
 int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t count, bool relin) {
   if (!count) return 0;
+  if (c->logn != 14) {
+    if (relin) { set_error("bmul_split: multiply + relinearise in one sequence is an N = 2^14 path"); return 1; }
+    return bmul_big(c, a, b, out, count);
+  }
   const size_t N = (size_t)c->n, PS = (size_t)c->dc.ps;
   const int L = c->L, nlm = c->L + c->nBsk;
   const size_t per_ct = bmul_scratch_words(c);
@@ -313,7 +364,7 @@ int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t coun
   if (chunk * lanes > count) chunk = (count + lanes - 1) / lanes;
   if (ensure_workspace(c, (size_t)lanes * chunk * per_ct * 8)) return 1;
   const size_t Xw = std::max((size_t)4 * nlm * N, (size_t)L * (L + 1) * PS);
-  const size_t lds = (size_t)nlm * 16 * kPos * 8;
+  const size_t lds = (size_t)nlm * 512 * 8;
   LaneScope scope(c, lanes);
   if (scope.fork()) return 1;
   int turn = 0;
@@ -324,9 +375,9 @@ int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t coun
     double *X = (double *)c->ws + (size_t)ln * chunk * per_ct, *Y = X + cc * Xw;
     const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
     u64 *po = out + off * (relin ? 2 : 3) * L * N;
-    hipLaunchKernelGGL((k_bmul_front<8, 8>), dim3((unsigned)(cc * 4 * 32)), dim3(512), lds, st, c->dc, pa, pb, X);
+    hipLaunchKernelGGL((k_bmul_front<14, 4, 8, 8>), dim3((unsigned)(cc * 4 * 32)), dim3(512), lds, st, c->dc, pa, pb, X);
     hipLaunchKernelGGL(k_bmul_mid, dim3((unsigned)(cc * nlm * 16)), dim3(256), 0, st, c->dc, (const double *)X, Y, nlm, L);
-    hipLaunchKernelGGL((k_bmul_back<8, 8>), dim3((unsigned)(cc * 3 * 32)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, relin ? 0 : 1);
+    hipLaunchKernelGGL((k_bmul_back<14, 4, 8, 8>), dim3((unsigned)(cc * 3 * 32)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, relin ? 0 : 1);
     ABC_HIP_CHECK(hipGetLastError());
     if (relin && bsplit_back14(c, st, cc, L, (const double *)X, Y, c->d_relin, po, 2 * (size_t)L * N, 1, po)) return 1;
   }

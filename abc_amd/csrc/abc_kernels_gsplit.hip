@@ -26,36 +26,6 @@ __device__ __forceinline__ double g_mulmod(double x, double y, double q, double 
   return __builtin_fma(-c, q, h) + l;
 }
 
-// radix-2^R pass over the 2^R values one thread holds, one from each block (block index = array index): global stages 0..R-1
-template <int R>
-__device__ __forceinline__ void fwd_cross(double (&x)[1 << R], const FpTable &t, const FpK &kk) {
-#pragma unroll
-  for (int u = 0; u < R; u++) {
-    const int half = 1 << (R - 1 - u);
-#pragma unroll
-    for (int k = 0; k < (1 << R); k++) {
-      if (k & half) continue;
-      FpArith::fwd(x[k], x[k | half], tw_load(t.tw + (1 << u) + (k >> (R - u))), kk);
-    }
-  }
-}
-template <int R>
-__device__ __forceinline__ void inv_cross(double (&x)[1 << R], const FpTable &t, const FpK &kk) {
-#pragma unroll
-  for (int u = R - 1; u >= 0; u--) {
-    const int half = 1 << (R - 1 - u);
-#pragma unroll
-    for (int k = 0; k < (1 << R); k++) {
-      if (k & half) continue;
-      FpArith::inv(x[k], x[k | half], tw_load(t.itw + (1 << u) + (k >> (R - u))), kk);
-    }
-    if (R > 4 && u == R - 4) {  // X = a + b doubles per stage: four stages on centred values stay below 2^53, a fifth needs this
-#pragma unroll
-      for (int k = 0; k < (1 << R); k++) x[k] = fp_centre(x[k], kk.q, kk.qinv);
-    }
-  }
-}
-
 // ---- G1a ----
 // MODE 0: multiply (a, b: [ct][2][nl][N], operand = a1 b1).  MODE 1: operand in NTT form at a + ct * a_stride (Galois gather).
 template <int LOGN, int MODE, bool GAL>

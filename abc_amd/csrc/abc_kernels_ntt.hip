@@ -381,6 +381,12 @@ int launch_ntt_inv_strided_part(abc_hip_ctx *c, u64 *d, const LimbMap &map, int 
                                       : launch_strided<4>(c, d, map, nl, total_limbs, false);
 }
 int big_block_log(void) { return kBigBlockLB; }
+// N > 2^14: only the block stages of the forward transform, in place, on limbs whose strided first stages a fused kernel has done
+// (abc_kernels_bmul.hip, k_bmul_front): raw doubles in, canonical NTT form out
+int launch_ntt_fwd_block_part(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
+  if (c->logn != 15 && c->logn != 16) { set_error("forward block part: N = 2^15 / 2^16 only"); return 1; }
+  return launch_block<kBigBlockLB>(c, d, map, nl, total_limbs, c->logn - kBigBlockLB, true);
+}
 
 int launch_ntt_fwd(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
   return launch_ntt(c, d, map, nl, total_limbs, true);

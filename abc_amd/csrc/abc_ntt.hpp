@@ -317,6 +317,37 @@ __device__ __forceinline__ void inv_pass_lds(typename A::E (&x)[16], const int (
   }
 }
 
+// ---- cross passes of the split transforms (abc_kernels_gsplit.hip, abc_kernels_bmul.hip) ----
+// radix-2^R pass over the 2^R values one thread holds, one from each block (block index = array index): global stages 0..R-1
+template <int R>
+__device__ __forceinline__ void fwd_cross(double (&x)[1 << R], const FpTable &t, const FpK &kk) {
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      FpArith::fwd(x[k], x[k | half], tw_load(t.tw + (1 << u) + (k >> (R - u))), kk);
+    }
+  }
+}
+template <int R>
+__device__ __forceinline__ void inv_cross(double (&x)[1 << R], const FpTable &t, const FpK &kk) {
+#pragma unroll
+  for (int u = R - 1; u >= 0; u--) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      FpArith::inv(x[k], x[k | half], tw_load(t.itw + (1 << u) + (k >> (R - u))), kk);
+    }
+    if (R > 4 && u == R - 4) {  // X = a + b doubles per stage: four stages on centred values stay below 2^53, a fifth needs this
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) x[k] = fp_centre(x[k], kk.q, kk.qinv);
+    }
+  }
+}
+
 // Index bookkeeping of one pass: group p has lo = p mod G, hi = p / G (G = 2^(LB-S-R)); its k-th element sits at
 // (hi << (LB-S)) + (k << logG) + lo.  Group ownership is wave-contiguous: lane l of wave w owns groups
 // w*64*NG + g*64 + l.  For the first pass (NG = 1) that is simply p = tid; for every later pass (S >= LB-10) a

@@ -105,14 +105,17 @@ def test_config5_bfv_depth8_chain(oracle_mod, capi):
     assert o.noise_budget(acc) > 0
 
 
-@pytest.mark.parametrize("generic", [False, True])
-@pytest.mark.parametrize("n,bits", [(32768, [49] * 4 + [50]), (65536, [49] * 8 + [50])])
+@pytest.mark.parametrize("generic", [False, True, "unfused_multiply"])
+@pytest.mark.parametrize("n,bits", [(32768, [49] * 4 + [50]), (32768, [49] * 8 + [50]), (65536, [49] * 8 + [50])])
 def test_big_ring_bfv_on_an_fp64_chain(n, bits, generic, oracle_mod, capi, monkeypatch):
     """BFV at N = 2^15 / 2^16 with every prime below 2^50 (config 5's alternative chain): the key switch takes the split
     kernels with a radix-32 / radix-64 cross pass (abc_kernels_gsplit.hip, k_bsplit_*); with ABC_HIP_NO_BSPLIT the generic
-    sequence.  Both must give the oracle's residues."""
-    if generic:
+    sequence.  Eight data limbs (the BFVDefault shape): the multiply takes abc_kernels_bmul.hip's fused extension / floor kernels
+    around the 4096-point block tails; ABC_HIP_NO_BMUL selects the separate kernels.  All must give the oracle's residues."""
+    if generic is True:
         monkeypatch.setenv("ABC_HIP_NO_BSPLIT", "1")
+    if generic == "unfused_multiply":
+        monkeypatch.setenv("ABC_HIP_NO_BMUL", "1")
     primes = oracle_mod.create_primes(n, bits)
     t = oracle_mod.plain_modulus_batching(n, 20)
     o, g = _pair(oracle_mod, capi, oracle_mod.BFV, n, primes, t, seed=77)
