@@ -63,6 +63,27 @@ __device__ __forceinline__ LaneMod lane_mod(const DevCtx &c, int mid) {
   return r;
 }
 
+// radix-2^R cross passes on the 2^R values of one column; R = 4 through the register pass of abc_ntt.hpp (the form the N = 2^14
+// key-switch kernels use)
+template <int R>
+__device__ __forceinline__ void m_fwd_cross(double (&x)[1 << R], const FpTable &t, const FpK &kk) {
+  if constexpr (R == 4) {
+    const int hi0[1] = {0};
+    fwd_pass<FpArith, 14, 0, 4>(x, hi0, t, kk, 0, 0);
+  } else {
+    fwd_cross<R>(x, t, kk);
+  }
+}
+template <int R>
+__device__ __forceinline__ void m_inv_cross(double (&x)[1 << R], const FpTable &t, const FpK &kk) {
+  if constexpr (R == 4) {
+    const int hi0[1] = {0};
+    inv_pass<FpArith, 14, 0, 4>(x, hi0, t, kk, 0, 0);
+  } else {
+    inv_cross<R>(x, t, kk);
+  }
+}
+
 }  // namespace
 
 // ---- M1 ----
@@ -122,7 +143,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__re
     double x[NBLK];
 #pragma unroll
     for (int kb = 0; kb < NBLK; kb++) x[kb] = dyn[(l * NBLK + kb) * P + p];
-    fwd_cross<R>(x, lm.t, lm.kk);
+    m_fwd_cross<R>(x, lm.t, lm.kk);
     double *__restrict__ dst = hA + ((ct * 4 + poly) * NLM + l) * N + (size_t)(pg * P) + p;
 #pragma unroll
     for (int kb = 0; kb < NBLK; kb++) dst[(size_t)kb << SH] = x[kb];
@@ -130,30 +151,36 @@ __global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__re
 }
 
 // ---- M2 ----
-__global__ __launch_bounds__(256) void k_bmul_mid(DevCtx c, const double *__restrict__ hA, double *__restrict__ hD, int nlm, int L) {
-  constexpr int LOGNB = 4;
-  constexpr size_t N = (size_t)1 << 14;
-  __shared__ double lds[4 * lds_words(10)];
-  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = threadIdx.x & 63;
-  const int blk = blockIdx.x & 15;
+// LB: block size of the tails (10 at N = 2^14: one wavefront per operand polynomial, 256 threads, 35 KiB; 12 at N = 2^15 / 2^16:
+// 256 threads per operand polynomial, 1024 threads, 139 KiB -- one workgroup per CU, but its 187 limb transfers per limb-block
+// shrink to 7: the separate forward-tail kernel wrote and the tensor kernel re-read every operand limb).  Groups of T = 2^LB / 16
+// threads run the block transforms of abc_ntt.hpp side by side; for LB > 10 those contain workgroup barriers, so all four groups
+// execute every transform call (the fourth group's inverse pass is a repeat of component 2 that stores nothing).
+template <int LOGN, int LB>
+__global__ __launch_bounds__(4 * ((1 << LB) / 16)) void k_bmul_mid(DevCtx c, const double *__restrict__ hA, double *__restrict__ hD, int nlm, int L) {
+  constexpr int LOGNB = LOGN - LB, T = (1 << LB) / 16, LW = lds_words(LB);
+  constexpr size_t N = (size_t)1 << LOGN;
+  extern __shared__ double dyn[];  // four transform buffers
+  const int G = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / T));  // operand polynomial / product component of this group
+  const int gt = threadIdx.x & (T - 1);
+  const int blk = blockIdx.x & ((1 << LOGNB) - 1);
   const int l = (int)((blockIdx.x >> LOGNB) % (unsigned)nlm);
   const size_t ct = (size_t)((blockIdx.x >> LOGNB) / (unsigned)nlm);
   const int mid = l < L ? l : c.id_bsk + (l - L);
   const Mod m = mod_at(c, mid);
   const FpTable t = fp_table(c, mid);
   const double q = m.qd, qinv = m.qinv;
-  const size_t base = (size_t)blk << 10;
-  double *buf = lds + W * lds_words(10);
-  {  // wavefront W: forward tail of operand polynomial W (a0, a1, b0, b1), centred result parked in LDS
-    const double *__restrict__ src = hA + ((ct * 4 + W) * nlm + l) * N + base;
-    ntt_fwd_block_a<10, FpArith>(
+  const size_t base = (size_t)blk << LB;
+  double *buf = dyn + G * LW;
+  {  // group G: forward tail of operand polynomial G (a0, a1, b0, b1), centred result parked in LDS
+    const double *__restrict__ src = hA + ((ct * 4 + G) * nlm + l) * N + base;
+    ntt_fwd_block_a<LB, FpArith>(
         buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = fp_centre(v, q, qinv); }, t,
-        m, LOGNB, blk, lane);
+        m, LOGNB, blk, gt);
   }
   __syncthreads();
-  for (int e = 2 * (int)threadIdx.x; e < 1024; e += 512) {  // dyadic tensor product, in place (a thread rewrites only what it read)
-    double *p0 = lds + lds_pad(e), *p1 = p0 + lds_words(10), *p2 = p1 + lds_words(10), *p3 = p2 + lds_words(10);
+  for (int e = 2 * (int)threadIdx.x; e < (1 << LB); e += 8 * T) {  // dyadic tensor product, in place (a thread rewrites only what it read)
+    double *p0 = dyn + lds_pad(e), *p1 = p0 + LW, *p2 = p1 + LW, *p3 = p2 + LW;
     const f64x2 a0 = *reinterpret_cast<const f64x2 *>(p0), a1 = *reinterpret_cast<const f64x2 *>(p1);
     const f64x2 b0 = *reinterpret_cast<const f64x2 *>(p2), b1 = *reinterpret_cast<const f64x2 *>(p3);
     f64x2 d;
@@ -168,10 +195,18 @@ __global__ __launch_bounds__(256) void k_bmul_mid(DevCtx c, const double *__rest
     *reinterpret_cast<f64x2 *>(p2) = d;
   }
   __syncthreads();
-  if (W < 3) {  // inverse tail of product component W; N^-1 belongs to the cross pass (M3)
-    double *__restrict__ dst = hD + ((ct * 3 + W) * nlm + l) * N + base;
-    ntt_inv_block_a<10, FpArith>(
-        buf, [&](int, int i) { return buf[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, LOGNB, blk, lane);
+  if (LB > 10 || G < 3) {  // inverse tail of product component G; N^-1 belongs to the cross pass (M3)
+    const bool live = G < 3;
+    const int comp = live ? G : 2;
+    // the fourth group of a barrier-synchronised transform works on a private copy of component 2 (its own buffer) and stores nothing
+    if (LB > 10 && !live) {
+      for (int i = gt; i < (1 << LB); i += T) buf[lds_pad(i)] = dyn[2 * LW + lds_pad(i)];
+    }
+    if (LB > 10) __syncthreads();
+    double *tb = live ? dyn + comp * LW : buf;
+    double *__restrict__ dst = hD + ((ct * 3 + comp) * nlm + l) * N + base;
+    ntt_inv_block_a<LB, FpArith>(
+        tb, [&](int, int i) { return tb[lds_pad(i)]; }, [&](int, int i, double v) { if (live) dst[i] = v; }, t, m, LOGNB, blk, gt);
   }
 }
 
@@ -197,7 +232,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
     double x[NBLK];
 #pragma unroll
     for (int kb = 0; kb < NBLK; kb++) x[kb] = fp_centre(src[(size_t)kb << SH], lm.kk.q, lm.kk.qinv);
-    inv_cross<R>(x, lm.t, lm.kk);
+    m_inv_cross<R>(x, lm.t, lm.kk);
 #pragma unroll
     for (int kb = 0; kb < NBLK; kb++) dyn[(l * NBLK + kb) * P + p] = fp_mul_lazy(x[kb], lm.inv_n_c, lm.inv_n_cq, lm.kk.q);
   }
@@ -277,7 +312,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
         double y[NBLK];
 #pragma unroll
         for (int kb = 0; kb < NBLK; kb++) y[kb] = x[kb];
-        fwd_cross<R>(y, t, kk);
+        m_fwd_cross<R>(y, t, kk);
         double *__restrict__ dst = part + ((ct * (L + 1) + I) * L + J) * PS + (size_t)(pg * P) + p;
 #pragma unroll
         for (int kb = 0; kb < NBLK; kb++) dst[(size_t)kb << SH] = y[kb];
@@ -335,8 +370,17 @@ static int bmul_big(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_
     else
       hipLaunchKernelGGL((k_bmul_front<15, 3, 8, 8>), dim3((unsigned)(cc * 4 * 64)), dim3(512), lds, st, c->dc, pa, pb, X);
     ABC_HIP_CHECK(hipGetLastError());
-    if (launch_ntt_fwd_block_part(c, (u64 *)X, map, nlm, cc * 4 * nlm)) return 1;
-    if (launch_bfv_tensor_inv_block(c, (const u64 *)X, (const u64 *)X + 2 * (size_t)nlm * N, 4 * (size_t)nlm * N, (u64 *)Y, map, nlm, cc)) return 1;
+    if (c->sw.no_bmul_mid) {  // A/B: block tails and tensor product as the separate kernels of the generic sequence
+      if (launch_ntt_fwd_block_part(c, (u64 *)X, map, nlm, cc * 4 * nlm)) return 1;
+      if (launch_bfv_tensor_inv_block(c, (const u64 *)X, (const u64 *)X + 2 * (size_t)nlm * N, 4 * (size_t)nlm * N, (u64 *)Y, map, nlm, cc))
+        return 1;
+    } else if (c->logn == 16) {
+      hipLaunchKernelGGL((k_bmul_mid<16, 12>), dim3((unsigned)(cc * nlm * 16)), dim3(1024), (size_t)(4 * lds_words(12)) * 8, st, c->dc,
+                         (const double *)X, Y, nlm, L);
+    } else {
+      hipLaunchKernelGGL((k_bmul_mid<15, 12>), dim3((unsigned)(cc * nlm * 8)), dim3(1024), (size_t)(4 * lds_words(12)) * 8, st, c->dc,
+                         (const double *)X, Y, nlm, L);
+    }
     if (c->logn == 16)
       hipLaunchKernelGGL((k_bmul_back<16, 4, 8, 8>), dim3((unsigned)(cc * 3 * 128)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, 1);
     else
@@ -376,7 +420,7 @@ int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t coun
     const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
     u64 *po = out + off * (relin ? 2 : 3) * L * N;
     hipLaunchKernelGGL((k_bmul_front<14, 4, 8, 8>), dim3((unsigned)(cc * 4 * 32)), dim3(512), lds, st, c->dc, pa, pb, X);
-    hipLaunchKernelGGL(k_bmul_mid, dim3((unsigned)(cc * nlm * 16)), dim3(256), 0, st, c->dc, (const double *)X, Y, nlm, L);
+    hipLaunchKernelGGL((k_bmul_mid<14, 10>), dim3((unsigned)(cc * nlm * 16)), dim3(256), (size_t)(4 * lds_words(10)) * 8, st, c->dc, (const double *)X, Y, nlm, L);
     hipLaunchKernelGGL((k_bmul_back<14, 4, 8, 8>), dim3((unsigned)(cc * 3 * 32)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, relin ? 0 : 1);
     ABC_HIP_CHECK(hipGetLastError());
     if (relin && bsplit_back14(c, st, cc, L, (const double *)X, Y, c->d_relin, po, 2 * (size_t)L * N, 1, po)) return 1;
