@@ -784,6 +784,81 @@ __global__ __launch_bounds__(256) void k_bsplit_finish_big(DevCtx c, const doubl
   }
 }
 
+// B4 through LDS for N = 2^15 / 2^16: the radix-32 / 64 inverse cross pass as TWO register passes of at most eight values with a
+// transposition in 16 KiB of LDS between them, instead of 32 / 64 values per thread (k_bsplit_finish_big<16>: 256 VGPRs, one
+// wavefront per SIMD, 1.6 TB/s on its bytes).  Workgroup ((ct, comp), I, group of 32 positions); stages R-1..RB run on RA
+// consecutive block indices (thread = (group of 2^RA blocks, position)), stages RB-1..0 on blocks 2^RA apart (thread = (block
+// index mod 2^RA, position)), which then finishes its 2^RB coefficients: N^-1, subtract the special limb, q_sp^-1, addend.
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_bsplit_finish_lds(DevCtx c, const double *__restrict__ half, const double *__restrict__ tco,
+                                                           const u64 *__restrict__ addend, size_t addend_stride, int add_c1,
+                                                           u64 *__restrict__ out, int nl) {
+  constexpr int R = LOGN - 10, NB = 1 << R, RA = 3, RB = R - RA, P = 32;
+  __shared__ double lds[NB * P];
+  const int pg = blockIdx.x & 31;
+  const int I = (int)((blockIdx.x >> 5) % (unsigned)nl);
+  const size_t cc = (size_t)((blockIdx.x >> 5) / (unsigned)nl);  // ct*2 + comp
+  const size_t ct = cc >> 1;
+  const int comp = (int)(cc & 1);
+  const size_t N = (size_t)1 << LOGN, PS = (size_t)c.ps;
+  const Mod m = mod_at(c, I);
+  const FpTable tb = fp_table(c, I);
+  const FpK kk = FpArith::consts(m);
+  const int tid = threadIdx.x;
+  {
+    const double *__restrict__ src = half + ((ct * (nl + 1) + I) * 2 + comp) * PS + (size_t)(pg * P);
+    for (int job = tid; job < (1 << RB) * P; job += 256) {
+      const int p = job & (P - 1), g = job >> 5;
+      double x[1 << RA];
+#pragma unroll
+      for (int j = 0; j < (1 << RA); j++) x[j] = fp_centre(src[(size_t)((g << RA) + j) * 1024 + p], kk.q, kk.qinv);
+#pragma unroll
+      for (int u = R - 1; u >= RB; u--) {
+        const int hf = 1 << (R - 1 - u);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) {
+          if (j & hf) continue;
+          FpArith::inv(x[j], x[j | hf], tw_load(tb.itw + (1 << u) + (((g << RA) + j) >> (R - u))), kk);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < (1 << RA); j++) lds[((g << RA) + j) * P + p] = fp_centre(x[j], kk.q, kk.qinv);
+    }
+  }
+  __syncthreads();
+  const u64 hm = reduce64(c.mods[c.K - 1].q >> 1, m);
+  const double fix = hm ? (double)(m.q - hm) : 0.0;
+  const ABC_CONST_AS DevConst *cst = (const ABC_CONST_AS DevConst *)c.cst;
+  const double inv = cst->inv_special_c[I], inv_q = cst->inv_special_cq[I];
+  const double *__restrict__ tsrc = tco + cc * PS + (size_t)(pg * P);
+  u64 *__restrict__ o = out + (cc * nl + I) * N + (size_t)(pg * P);
+  const bool add = addend && (comp == 0 || add_c1);
+  const u64 *__restrict__ cin = add ? addend + ct * addend_stride + ((size_t)comp * nl + I) * N + (size_t)(pg * P) : nullptr;
+  for (int job = tid; job < (1 << RA) * P; job += 256) {
+    const int p = job & (P - 1), j = job >> 5;
+    double y[1 << RB];
+#pragma unroll
+    for (int h = 0; h < (1 << RB); h++) y[h] = lds[((h << RA) + j) * P + p];
+#pragma unroll
+    for (int u = RB - 1; u >= 0; u--) {
+      const int hf = 1 << (RB - 1 - u);
+#pragma unroll
+      for (int h = 0; h < (1 << RB); h++) {
+        if (h & hf) continue;
+        FpArith::inv(y[h], y[h | hf], tw_load(tb.itw + (1 << u) + (h >> (RB - u))), kk);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < (1 << RB); h++) {
+      const size_t e = (size_t)((h << RA) + j) * 1024 + p;
+      const double d = fp_mul_lazy(y[h], m.inv_n_c, m.inv_n_cq, m.qd) - (tsrc[e] + fix);
+      double r = fp_mul_lazy(d, inv, inv_q, m.qd);
+      if (add) r += fp_from_u64(cin[e]);
+      o[e] = fp_to_canon(r, m.qd, m.qinv);
+    }
+  }
+}
+
 bool bsplit_big_applies(const abc_hip_ctx *c, int nl) {
   if ((c->logn != 15 && c->logn != 16) || c->scheme != 1 || !c->use_fp || c->sw.no_bsplit || c->sw.no_gsplit || nl < 1 || nl > 8) return false;
   for (int j = 0; j < c->K; j++)
@@ -814,8 +889,12 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
   }
 #undef ABC_BSPB
   hipLaunchKernelGGL((k_bsplit_tcoef<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, half, tco, nl);
-  hipLaunchKernelGGL((k_bsplit_finish_big<LOGN>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
-                     addend_stride, add_c1, out, nl);
+  if (c->sw.no_finish_lds)
+    hipLaunchKernelGGL((k_bsplit_finish_big<LOGN>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
+                       addend_stride, add_c1, out, nl);
+  else
+    hipLaunchKernelGGL((k_bsplit_finish_lds<LOGN>), dim3((unsigned)(cc * 2 * nl * 32)), dim3(256), 0, st, c->dc, half, tco, addend,
+                       addend_stride, add_c1, out, nl);
   ABC_HIP_CHECK(hipGetLastError());
   return 0;
 }
