@@ -784,6 +784,72 @@ __global__ __launch_bounds__(256) void k_bsplit_finish_big(DevCtx c, const doubl
   }
 }
 
+// B1 through LDS for N = 2^15 / 2^16: workgroup (ct, digit J, group of 32 positions) reads the digit ONCE and runs the forward
+// cross pass modulo every key prime I from registers -- stages 0..RB-1 on blocks 2^RA apart, transposition through 16 KiB of LDS,
+// stages RB..R-1 on 2^RA consecutive blocks: at most eight values per thread (k_bsplit_pass0<16>: 64 values, 209 VGPRs, and one
+// read of the digit per key prime: 72 limb reads per ciphertext where 8 do).
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_bsplit_pass0_lds(DevCtx c, const u64 *__restrict__ src, size_t src_stride, double *__restrict__ part,
+                                                          int nl) {
+  constexpr int R = LOGN - 10, NB = 1 << R, RA = 3, RB = R - RA, P = 32;
+  __shared__ double lds[NB * P];
+  const int pg = blockIdx.x & 31;
+  const int J = (int)((blockIdx.x >> 5) % (unsigned)nl);
+  const size_t ct = (size_t)((blockIdx.x >> 5) / (unsigned)nl);
+  const size_t N = (size_t)1 << LOGN, PS = (size_t)c.ps;
+  const int tid = threadIdx.x;
+  constexpr int JOBS1 = (1 << RA) * P, JOBS2 = (1 << RB) * P;  // 256 and 256 (R = 6) / 128 (R = 5)
+  const bool w1 = tid < JOBS1, w2 = tid < JOBS2;
+  const int p = tid & (P - 1), jg = tid >> 5;  // phase 1: j = jg (block index mod 2^RA); phase 2: g = jg (group of 2^RA blocks)
+  const u64 *__restrict__ sp = src + ct * src_stride + (size_t)J * N + (size_t)(pg * P);
+  double y0[1 << RB];
+  if (w1) {
+#pragma unroll
+    for (int h = 0; h < (1 << RB); h++) y0[h] = fp_from_u64(sp[(size_t)((h << RA) + jg) * 1024 + p]);
+  }
+  for (int I = 0; I <= nl; I++) {
+    const int ki = (I == nl) ? c.K - 1 : I;
+    const Mod m = mod_at(c, ki);
+    const FpTable t = fp_table(c, ki);
+    const FpK kk = FpArith::consts(m);
+    if (w1) {
+      double y[1 << RB];
+#pragma unroll
+      for (int h = 0; h < (1 << RB); h++) y[h] = y0[h];
+#pragma unroll
+      for (int u = 0; u < RB; u++) {
+        const int hf = 1 << (RB - 1 - u);
+#pragma unroll
+        for (int h = 0; h < (1 << RB); h++) {
+          if (h & hf) continue;
+          FpArith::fwd(y[h], y[h | hf], tw_load(t.tw + (1 << u) + (h >> (RB - u))), kk);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < (1 << RB); h++) lds[((h << RA) + jg) * P + p] = y[h];
+    }
+    __syncthreads();
+    if (w2) {
+      double x[1 << RA];
+#pragma unroll
+      for (int j = 0; j < (1 << RA); j++) x[j] = lds[((jg << RA) + j) * P + p];
+#pragma unroll
+      for (int u = RB; u < R; u++) {
+        const int hf = 1 << (R - 1 - u);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) {
+          if (j & hf) continue;
+          FpArith::fwd(x[j], x[j | hf], tw_load(t.tw + (1 << u) + (((jg << RA) + j) >> (R - u))), kk);
+        }
+      }
+      double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + J) * PS + (size_t)(pg * P) + p;
+#pragma unroll
+      for (int j = 0; j < (1 << RA); j++) dst[(size_t)((jg << RA) + j) * 1024] = x[j];
+    }
+    __syncthreads();  // the next prime's first pass rewrites the tile
+  }
+}
+
 // B4 through LDS for N = 2^15 / 2^16: the radix-32 / 64 inverse cross pass as TWO register passes of at most eight values with a
 // transposition in 16 KiB of LDS between them, instead of 32 / 64 values per thread (k_bsplit_finish_big<16>: 256 VGPRs, one
 // wavefront per SIMD, 1.6 TB/s on its bytes).  Workgroup ((ct, comp), I, group of 32 positions); stages R-1..RB run on RA
@@ -872,8 +938,11 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
   constexpr int NB = 1 << (LOGN - 10);
   const size_t PS = (size_t)c->dc.ps;
   double *part = scratch, *half = part + cc * (size_t)nl * (nl + 1) * PS, *tco = half + cc * 2 * (size_t)(nl + 1) * PS;
-  hipLaunchKernelGGL((k_bsplit_pass0<LOGN>), dim3((unsigned)(cc * nl * (nl + 1) * 4)), dim3(256), 0, st, c->dc, target, target_stride, part,
-                     nl);
+  if (c->sw.no_finish_lds)
+    hipLaunchKernelGGL((k_bsplit_pass0<LOGN>), dim3((unsigned)(cc * nl * (nl + 1) * 4)), dim3(256), 0, st, c->dc, target, target_stride, part,
+                       nl);
+  else
+    hipLaunchKernelGGL((k_bsplit_pass0_lds<LOGN>), dim3((unsigned)(cc * nl * 32)), dim3(256), 0, st, c->dc, target, target_stride, part, nl);
   const dim3 g((unsigned)(cc * (nl + 1) * NB));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
 #define ABC_BSPB(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
