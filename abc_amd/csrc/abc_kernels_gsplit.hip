@@ -79,10 +79,124 @@ __global__ __launch_bounds__(256) void k_gsplit_inv_tails(DevCtx c, const u64 *_
   }
 }
 
+// ---- radix-32 / 64 cross passes as two register passes with a transposition through an LDS tile [2^R blocks][32 positions] ----
+// (N = 2^15 / 2^16; 256 threads).  In registers a radix-32 pass is 32 values per thread and the kernels around it held two such sets
+// (k_gsplit_cross<15>: 256 VGPRs, one wavefront per SIMD; k_gsplit_pass<15>: 184).  Here a thread never holds more than eight:
+//   inverse: stages R-1..RB on eight consecutive blocks (thread (group g, position p)), tile, stages RB-1..0 on the 2^RB blocks
+//            j, j + 8, ... (thread (j, p)) -- which is where the values stay;
+//   forward: stages 0..RB-1 from that same register layout, tile, stages RB..R-1 on eight consecutive blocks, store.
+// The forward half rewrites exactly the tile words its thread read last, so one tile serves a whole kernel with two barriers per pass.
+template <int R>
+struct CrossLds {
+  static constexpr int RA = 3, RB = R - RA, P = 32, NB = 1 << R;
+  template <class Load>
+  __device__ __forceinline__ static void inverse(double *lds, int tid, Load load, const FpTable &t, const FpK &kk, double (&x)[1 << RB]) {
+    const int p = tid & (P - 1), jg = tid >> 5;
+    if (tid < (1 << RB) * P) {
+      double v[1 << RA];
+#pragma unroll
+      for (int j = 0; j < (1 << RA); j++) v[j] = fp_centre(load((jg << RA) + j, p), kk.q, kk.qinv);
+#pragma unroll
+      for (int u = R - 1; u >= RB; u--) {
+        const int hf = 1 << (R - 1 - u);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) {
+          if (j & hf) continue;
+          FpArith::inv(v[j], v[j | hf], tw_load(t.itw + (1 << u) + (((jg << RA) + j) >> (R - u))), kk);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < (1 << RA); j++) lds[((jg << RA) + j) * P + p] = fp_centre(v[j], kk.q, kk.qinv);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < (1 << RB); h++) x[h] = lds[((h << RA) + jg) * P + p];
+#pragma unroll
+    for (int u = RB - 1; u >= 0; u--) {
+      const int hf = 1 << (RB - 1 - u);
+#pragma unroll
+      for (int h = 0; h < (1 << RB); h++) {
+        if (h & hf) continue;
+        FpArith::inv(x[h], x[h | hf], tw_load(t.itw + (1 << u) + (h >> (RB - u))), kk);
+      }
+    }
+  }
+  // x: values of blocks j + 8 h at position p, thread (j = tid >> 5, p = tid & 31); store(block, position, value)
+  template <class Store>
+  __device__ __forceinline__ static void forward(double *lds, int tid, const double (&x)[1 << RB], double add, const FpTable &t, const FpK &kk,
+                                                 Store store) {
+    const int p = tid & (P - 1), jg = tid >> 5;
+    double y[1 << RB];
+#pragma unroll
+    for (int h = 0; h < (1 << RB); h++) y[h] = x[h] + add;
+#pragma unroll
+    for (int u = 0; u < RB; u++) {
+      const int hf = 1 << (RB - 1 - u);
+#pragma unroll
+      for (int h = 0; h < (1 << RB); h++) {
+        if (h & hf) continue;
+        FpArith::fwd(y[h], y[h | hf], tw_load(t.tw + (1 << u) + (h >> (RB - u))), kk);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < (1 << RB); h++) lds[((h << RA) + jg) * P + p] = y[h];
+    __syncthreads();
+    if (tid < (1 << RB) * P) {
+      double v[1 << RA];
+#pragma unroll
+      for (int j = 0; j < (1 << RA); j++) v[j] = lds[((jg << RA) + j) * P + p];
+#pragma unroll
+      for (int u = RB; u < R; u++) {
+        const int hf = 1 << (R - 1 - u);
+#pragma unroll
+        for (int j = 0; j < (1 << RA); j++) {
+          if (j & hf) continue;
+          FpArith::fwd(v[j], v[j | hf], tw_load(t.tw + (1 << u) + (((jg << RA) + j) >> (R - u))), kk);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < (1 << RA); j++) store((jg << RA) + j, p, v[j]);
+    }
+    __syncthreads();  // the next pass rewrites the tile
+  }
+};
+
 // ---- G1b ----
+// LOGN = 14: registers only, grid (ct, j, quarter of the positions).  LOGN > 14: through CrossLds, grid (ct, j, group of 32 positions).
 template <int LOGN>
 __global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__restrict__ hinv, double *__restrict__ part, int nl, int pack) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  if constexpr (LOGN > 14) {
+    using X = CrossLds<LOGNB>;
+    __shared__ double lds[NB * X::P];
+    const int pg = blockIdx.x & 31, tid = threadIdx.x;
+    const int j = (int)((blockIdx.x >> 5) % (unsigned)nl);
+    const size_t ct = (size_t)((blockIdx.x >> 5) / (unsigned)nl);
+    const size_t PS = (size_t)c.ps;
+    double x[1 << X::RB];
+    {
+      const Mod m = mod_at(c, j);
+      const FpTable t = fp_table(c, j);
+      const FpK kk = FpArith::consts(m);
+      const double *__restrict__ src = hinv + (ct * nl + j) * PS + (size_t)(pg * X::P);
+      X::inverse(lds, tid, [&](int k, int p) { return src[((size_t)k << 10) + p]; }, t, kk, x);
+#pragma unroll
+      for (int h = 0; h < (1 << X::RB); h++) {  // canonical [0, q_j) as a double
+        const double w = fp_centre(fp_mul_lazy(x[h], m.inv_n_c, m.inv_n_cq, m.qd), m.qd, m.qinv);
+        x[h] = w < 0.0 ? w + m.qd : w;
+      }
+    }
+    for (int I = 0; I <= nl; I++) {
+      if (I == j) continue;  // workgroup-uniform
+      const int ki = (I == nl) ? c.K - 1 : I;
+      const Mod m = mod_at(c, ki);
+      const FpTable t = fp_table(c, ki);
+      const FpK kk = FpArith::consts(m);
+      double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + j) * PS + (size_t)(pg * X::P);
+      X::forward(lds, tid, x, 0.0, t, kk, [&](int k, int p, double v) { dst[((size_t)k << 10) + p] = v; });
+    }
+    return;
+  }
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
   const int j = (int)((blockIdx.x >> 2) % (unsigned)nl);
   const size_t ct = (size_t)((blockIdx.x >> 2) / (unsigned)nl);
@@ -223,6 +337,38 @@ __global__ __launch_bounds__(NL * 64, (ALL && NL == 8) ? 4 : 1) void k_gsplit_sp
 template <int LOGN>
 __global__ __launch_bounds__(256) void k_gsplit_pass(DevCtx c, const double *__restrict__ tsp_half, double *__restrict__ tpart, int nl) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
+  if constexpr (LOGN > 14) {  // through CrossLds, grid ((ct, comp), group of 32 positions)
+    using X = CrossLds<LOGNB>;
+    __shared__ double lds[NB * X::P];
+    const int pg = blockIdx.x & 31, tid = threadIdx.x;
+    const size_t cc = blockIdx.x >> 5;
+    const size_t PS = (size_t)c.ps;
+    double x[1 << X::RB];
+    {
+      const Mod ms = mod_at(c, c.K - 1);
+      const FpTable ts = fp_table(c, c.K - 1);
+      const FpK ks = FpArith::consts(ms);
+      const double *__restrict__ src = tsp_half + cc * PS + (size_t)(pg * X::P);
+      X::inverse(lds, tid, [&](int k, int p) { return src[((size_t)k << 10) + p]; }, ts, ks, x);
+      const double half = (double)(ms.q >> 1);
+#pragma unroll
+      for (int h = 0; h < (1 << X::RB); h++) {
+        const double w = fp_centre(fp_mul_lazy(x[h], ms.inv_n_c, ms.inv_n_cq, ms.qd) + half, ms.qd, ms.qinv);
+        x[h] = w < 0.0 ? w + ms.qd : w;
+      }
+    }
+    const u64 halfq = c.mods[c.K - 1].q >> 1;
+    for (int j = 0; j < nl; j++) {
+      const Mod m = mod_at(c, j);
+      const FpTable t = fp_table(c, j);
+      const FpK kk = FpArith::consts(m);
+      const u64 hm = reduce64(halfq, m);
+      const double fix = hm ? (double)(m.q - hm) : 0.0;
+      double *__restrict__ dst = tpart + (cc * nl + j) * PS + (size_t)(pg * X::P);
+      X::forward(lds, tid, x, fix, t, kk, [&](int k, int p, double v) { dst[((size_t)k << 10) + p] = v; });
+    }
+    return;
+  }
   const size_t cc = blockIdx.x >> 2;
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
   const size_t PS = (size_t)c.ps;
@@ -502,7 +648,7 @@ template <int LOGN>
 static void launch_gsplit_front(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, int mode, const u64 *opa, const u64 *opb,
                                 size_t opa_stride, double *hinv, double *part, u32 gelt, int pack = 0) {
   constexpr int NB = 1 << (LOGN - 10);
-  const dim3 g1((unsigned)(((cc + 3) / 4) * nl * NB)), g2((unsigned)(cc * nl * 4));
+  const dim3 g1((unsigned)(((cc + 3) / 4) * nl * NB)), g2((unsigned)(cc * nl * (LOGN > 14 ? 32 : 4)));
   const size_t lds = (size_t)(4 * lds_words(10)) * 8 + 1024 * 16;
   if (mode == 0)
     hipLaunchKernelGGL((k_gsplit_inv_tails<LOGN, 0, false>), g1, dim3(256), lds, st, c->dc, opa, opb, 0, hinv, nl, (int)cc, 0u);
@@ -538,7 +684,7 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
       default: ABC_GSPD(15); break;
     }
 #undef ABC_GSPD
-    hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp, tpart, nl);
+    hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * (LOGN > 14 ? 32 : 4))), dim3(256), 0, st, c->dc, tsp, tpart, nl);
     if (mode == 0)
       hipLaunchKernelGGL((k_gsplit_main_deep<LOGN, 0, false>), gmain, dim3(1024), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,
                          opb_stride, add_c1, key, out, gelt, nl, 0xfedcba9876543210ull, nl);
@@ -552,7 +698,7 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   }
 #define ABC_GSP(NLV)                                                                                                                    \
   hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp, (int)cc);                            \
-  hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, tsp, tpart, nl);                     \
+  hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * (LOGN > 14 ? 32 : 4))), dim3(256), 0, st, c->dc, tsp, tpart, nl);  \
   if (mode == 0)                                                                                                                        \
     hipLaunchKernelGGL((k_gsplit_main<LOGN, 0, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,  \
                        opb_stride, add_c1, key, out, gelt, 0x76543210u, nl);                                                                             \
