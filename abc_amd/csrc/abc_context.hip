@@ -35,6 +35,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_bsplit = env_on("ABC_HIP_NO_BSPLIT");
   s.no_mixed = env_on("ABC_HIP_NO_MIXED");
   s.no_pack = env_on("ABC_HIP_NO_PACK");
+  s.no_key_twin = env_on("ABC_HIP_NO_KEY_TWIN");
   s.no_bmul = env_on("ABC_HIP_NO_BMUL");
   s.no_bmul_mid = env_on("ABC_HIP_NO_BMUL_MID");
   s.no_finish_lds = env_on("ABC_HIP_NO_FINISH_LDS");
@@ -702,6 +703,7 @@ void abc_hip_ctx_destroy(abc_hip_ctx *c) {
   (void)hipDeviceSynchronize();
   (void)hipFree(c->d_mods); (void)hipFree(c->d_tw); (void)hipFree(c->d_ftw); (void)hipFree(c->d_cst); (void)hipFree(c->d_cstf);
   (void)hipFree(c->d_slot_map);
+  drop_key_twins(c, nullptr);
   (void)hipFree(c->d_sk); (void)hipFree(c->d_pk); (void)hipFree(c->d_relin);
   for (auto &kv : c->d_galois) (void)hipFree(kv.second);
   (void)hipFree(c->ws);
@@ -922,6 +924,7 @@ int abc_hip_keygen_secure(abc_hip_ctx *c) {
 }
 static int load_key(abc_hip_ctx *c, uint64_t **slot, const uint64_t *h, size_t words) {
   NOT_CAPTURABLE(c, "key upload");
+  if (*slot) drop_key_twins(c, *slot);  // the mirror of the words about to be overwritten
   if (!*slot) ABC_HIP_CHECK(hipMalloc(slot, words * 8));
   ABC_HIP_CHECK(hipMemcpy(*slot, h, words * 8, hipMemcpyHostToDevice));
   return 0;

@@ -155,7 +155,7 @@ struct abc_hip_ctx {
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
   struct Switches {
-    bool no_fused = false, no_split = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, no_bsplit = false, no_mixed = false, no_pack = false, no_bmul = false, no_bmul_mid = false, no_finish_lds = false, no_tensor_intt = false;
+    bool no_fused = false, no_split = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, no_bsplit = false, no_mixed = false, no_pack = false, no_key_twin = false, no_bmul = false, no_bmul_mid = false, no_finish_lds = false, no_tensor_intt = false;
     bool no_galois_fusion = false;
     size_t chunk = 0, few_limbs = 48, lean_limit = 96, bfv_scratch_mb = 0, pass0_target_limit = 128;
     int lanes = 2;
@@ -167,6 +167,9 @@ struct abc_hip_ctx {
   // keys (device)
   uint64_t *d_sk = nullptr, *d_pk = nullptr, *d_relin = nullptr;
   std::map<uint32_t, uint64_t *> d_galois;
+  // fp64 twins of key-switching keys (centred doubles, same layout), built on first use by the fp64 split kernels, dropped when the
+  // key they mirror is rewritten (abc_kernels_fused.hip, key_twin)
+  std::unordered_map<const uint64_t *, double *> key_twins;
   std::vector<uint32_t> galois_order;
   // workspace (kernel-sequence scratch) and three caller-level arenas (products, rotation ping-pong buffers);
   // all grow on demand and are reused, so steady-state calls perform no hipMalloc / hipFree
@@ -259,6 +262,9 @@ int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u6
                size_t addend_stride, bool add_c1);
 int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
                   size_t addend_stride, int add_c1, u64 *out);
+// the fp64 twin of a key-switching key (nullptr: not available -- capture in progress and not built yet, or allocation failed)
+const double *key_twin(abc_hip_ctx *c, const u64 *key);
+void drop_key_twins(abc_hip_ctx *c, const u64 *key /* nullptr: all */);
 // internal lanes (streams forked off the context's stream): chunks of one call alternate over them (abc_kernels_fused.hip)
 int fork_lanes(abc_hip_ctx *c, int lanes);
 int join_lanes(abc_hip_ctx *c, int lanes);

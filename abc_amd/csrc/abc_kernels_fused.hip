@@ -29,6 +29,8 @@
 //                         it, subtract, scale by q_sp^-1, add c0 / c1.  BFV: inverse-transform the accumulated limb,
 //                         then the same subtract / scale / add in coefficient form
 // Algorithmic HBM bytes per multiply: 8N(6L + 2L(L+1)); measured: DESIGN.md section 4.
+#include <type_traits>
+
 #include "abc_context.hpp"
 
 namespace abc {
@@ -254,6 +256,52 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_ks_moddown_bfv(DevCtx 
           o[i] = mul_shoup(sub_mod(scale_inv_n(v, m), x, m.q), inv, inv_s, m.q);
         },
         t, m, 0, 0);
+  }
+}
+
+// ---- fp64 twins of key-switching keys -----------------------------------------------------------------------------------
+// The split kernels multiply every key word into an fp64 residue: as u64 it costs a conversion per use (two instructions, sixteen
+// words per thread of the last step); as a centred double, converted once when the key is first used, nothing.  Same layout
+// [digit][2][K][N]; words modulo primes above 2^52 convert inexactly and are never read (the fp64 kernels touch fp64-capable
+// primes only).
+__global__ __launch_bounds__(256) void k_key_to_fp(DevCtx c, const u64 *__restrict__ key, double *__restrict__ keyf, size_t words) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
+    const int kp = (int)((i >> c.logn) % (size_t)c.K);
+    const u64 q = c.mods[kp].q, v = key[i];
+    keyf[i] = v > (q >> 1) ? -(double)(q - v) : (double)v;
+  }
+}
+static const double *key_twin_lookup(const abc_hip_ctx *c, const u64 *key) {  // no building: safe after the lanes have forked
+  if (c->sw.no_key_twin) return nullptr;
+  auto it = c->key_twins.find(key);
+  return it == c->key_twins.end() ? nullptr : it->second;
+}
+// call BEFORE fork_lanes: the conversion runs on c->stream and the lanes wait for an event recorded behind it
+const double *key_twin(abc_hip_ctx *c, const u64 *key) {
+  if (c->sw.no_key_twin || !key) return nullptr;
+  auto it = c->key_twins.find(key);
+  if (it != c->key_twins.end()) return it->second;
+  if (c->capture_active) return nullptr;  // built by the eager pass that precedes every recording
+  double *d = nullptr;
+  const size_t words = c->key_words();
+  if (hipMalloc(&d, words * 8) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  hipLaunchKernelGGL(k_key_to_fp, dim3(stream_grid(words, 256)), dim3(256), 0, c->stream, c->dc, key, d, words);
+  c->key_twins[key] = d;
+  return d;
+}
+void drop_key_twins(abc_hip_ctx *c, const u64 *key) {
+  if (c->key_twins.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  if (!key) {
+    for (auto &kv : c->key_twins) (void)hipFree(kv.second);
+    c->key_twins.clear();
+    return;
+  }
+  auto it = c->key_twins.find(key);
+  if (it != c->key_twins.end()) {
+    (void)hipFree(it->second);
+    c->key_twins.erase(it);
   }
 }
 
@@ -640,7 +688,8 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_split2_tensor_pass0_fp(DevCt
 // together); NL = 0: any nl <= 12.
 template <int NL>
 __global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split_special_fp(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
-                                                                         double *__restrict__ tsp_half, int nl_rt) {
+                                                                         const double *__restrict__ keyf, double *__restrict__ tsp_half,
+                                                                         int nl_rt) {
   extern __shared__ double dyn[];  // max(nl, 2) buffers of one 1024-point block each
   const int nl = NL ? NL : nl_rt;
   const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -666,12 +715,20 @@ __global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split_special_fp(DevCtx 
     for (int Jx = 0; Jx < (NL ? NL : 12); Jx++) {
       if (!NL && Jx >= nl) break;
       const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
-      const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
-      const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
-      s0[0] += fp_mulmod(v.x, fp_from_u64(k0.x), q, qinv);
-      s0[1] += fp_mulmod(v.y, fp_from_u64(k0.y), q, qinv);
-      s1[0] += fp_mulmod(v.x, fp_from_u64(k1.x), q, qinv);
-      s1[1] += fp_mulmod(v.y, fp_from_u64(k1.y), q, qinv);
+      const size_t i0 = (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e, i1 = i0 + (size_t)c.K * N;
+      f64x2 k0, k1;
+      if (keyf) {  // the key's fp64 twin (workgroup-uniform): no conversion
+        k0 = *reinterpret_cast<const f64x2 *>(keyf + i0);
+        k1 = *reinterpret_cast<const f64x2 *>(keyf + i1);
+      } else {
+        const u64x2 r0 = *reinterpret_cast<const u64x2 *>(key + i0), r1 = *reinterpret_cast<const u64x2 *>(key + i1);
+        k0.x = fp_from_u64(r0.x); k0.y = fp_from_u64(r0.y);
+        k1.x = fp_from_u64(r1.x); k1.y = fp_from_u64(r1.y);
+      }
+      s0[0] += fp_mulmod(v.x, k0.x, q, qinv);
+      s0[1] += fp_mulmod(v.y, k0.y, q, qinv);
+      s1[0] += fp_mulmod(v.x, k1.x, q, qinv);
+      s1[1] += fp_mulmod(v.y, k1.y, q, qinv);
       if (Jx == 7) {  // eight products of magnitude < q stay below 2^53; re-centre before adding more
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -699,7 +756,8 @@ __global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split_special_fp(DevCtx 
 static void launch_split_special(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl, const double *part, const u64 *key, double *tsp_half) {
   const dim3 grid((unsigned)(cc * 16)), block(64 * nl);
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
-#define ABC_SP(NLV) hipLaunchKernelGGL((k_split_special_fp<NLV>), grid, block, lds, st, c->dc, part, key, tsp_half, nl)
+  const double *keyf = key_twin_lookup(c, key);
+#define ABC_SP(NLV) hipLaunchKernelGGL((k_split_special_fp<NLV>), grid, block, lds, st, c->dc, part, key, keyf, tsp_half, nl)
   switch (nl) {
     case 1: ABC_SP(1); break;
     case 2: ABC_SP(2); break;
@@ -905,7 +963,7 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
                                                                    const double *__restrict__ tpart, const u64 *__restrict__ opa,
                                                                    const u64 *__restrict__ opb, size_t opa_stride, size_t opb_stride,
                                                                    int add_c1, const u64 *__restrict__ key, u64 *__restrict__ out, u32 gelt,
-                                                                   u32 imap, int ni, int pack) {
+                                                                   u32 imap, int ni, int pack, const double *__restrict__ keyf) {
   // grid (ct, slot, block), slot < ni; the data prime of a slot is nibble `slot` of imap (all of them: 0x76543210, ni = nl; a subset
   // when a chain mixes fp64-capable and wider primes: abc_kernels_isplit.hip)
   // pack: the half-done limbs of `part` / `tpart` modulo primes of at most 48 bits arrive packed (abc_ntt.hpp)
@@ -951,10 +1009,13 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
     }
   }
   auto load_pair = [&](int e, PairOps<MODE, NL> &o) {
+    // key words: 16 raw bytes per (digit, component) either way -- the key's fp64 twin where it exists (keyf, workgroup-uniform:
+    // the words ARE the doubles), the u64 key otherwise (converted when used, after the transform)
+    const u64 *kw = keyf ? reinterpret_cast<const u64 *>(keyf) : key;
 #pragma unroll
     for (int Jx = 0; Jx < NL; Jx++) {
-      o.k0[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + I) * N + base + e);
-      o.k1[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + I) * N + base + e);
+      o.k0[Jx] = *reinterpret_cast<const u64x2 *>(kw + (((size_t)Jx * 2 + 0) * c.K + I) * N + base + e);
+      o.k1[Jx] = *reinterpret_cast<const u64x2 *>(kw + (((size_t)Jx * 2 + 1) * c.K + I) * N + base + e);
     }
     if (MODE == 0) {
       const u64 *pa = opa + ct * 2 * pw + (size_t)I * N + base + e, *pb = opb + ct * 2 * pw + (size_t)I * N + base + e;
@@ -1007,7 +1068,9 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
   }
   __syncthreads();
   const double *tt0 = dyn + (nl - 1) * lds_words(10), *tt1 = dyn + nl * lds_words(10);
-  auto compute_pair = [&](int e, const PairOps<MODE, NL> &o) {
+  auto compute_pair = [&](int e, const PairOps<MODE, NL> &o, auto twin) {
+    constexpr bool TW = decltype(twin)::value;
+    auto kd = [](u64 w) { return TW ? __longlong_as_double((long long)w) : fp_from_u64(w); };
     double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0}, d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0};
 #pragma unroll
     for (int Jx = 0; Jx < NL; Jx++) {
@@ -1036,10 +1099,10 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
         x[0] = v.x;
         x[1] = v.y;
       }
-      s0[0] += fp_mulmod(x[0], fp_from_u64(o.k0[Jx].x), q, qinv);
-      s0[1] += fp_mulmod(x[1], fp_from_u64(o.k0[Jx].y), q, qinv);
-      s1[0] += fp_mulmod(x[0], fp_from_u64(o.k1[Jx].x), q, qinv);
-      s1[1] += fp_mulmod(x[1], fp_from_u64(o.k1[Jx].y), q, qinv);
+      s0[0] += fp_mulmod(x[0], kd(o.k0[Jx].x), q, qinv);
+      s0[1] += fp_mulmod(x[1], kd(o.k0[Jx].y), q, qinv);
+      s1[0] += fp_mulmod(x[0], kd(o.k1[Jx].x), q, qinv);
+      s1[1] += fp_mulmod(x[1], kd(o.k1[Jx].y), q, qinv);
       if (Jx == 7) {
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -1057,7 +1120,8 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
     r.y = fp_to_canon(fp_mul_lazy(s1[1] - u1.y, inv, inv_q, q) + d1[1], q, qinv);
     *reinterpret_cast<u64x2 *>(out + ((ct * 2 + 1) * nl + I) * N + base + e) = r;
   };
-  compute_pair(2 * (int)threadIdx.x, ops);
+  if (keyf) compute_pair(2 * (int)threadIdx.x, ops, std::true_type{});  // workgroup-uniform
+  else compute_pair(2 * (int)threadIdx.x, ops, std::false_type{});
 }
 
 template <int MODE, bool GAL>
@@ -1071,7 +1135,8 @@ static bool launch_split4_main(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   const size_t lds = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
 #define ABC_TM4(NLV)                                                                                                                 \
   hipLaunchKernelGGL((k_split4_main_fp<MODE, GAL, NLV>), grid, block, lds, st, c->dc, part, tpart, opa, opb, opa_stride, opb_stride, \
-                     add_c1, key, out, gelt, imap, ni, pack)
+                     add_c1, key, out, gelt, imap, ni, pack, keyf)
+  const double *keyf = key_twin_lookup(c, key);
   switch (nl) {
     case 1: ABC_TM4(1); break;
     case 2: ABC_TM4(2); break;
@@ -1229,6 +1294,7 @@ static int run_isplit(abc_hip_ctx *c, int mode, const u64 *opa, const u64 *opb, 
   const ChunkPlan p = plan_chunks(c, nl, count);
   const size_t per_ct = isplit_scratch_words(c, nl);
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
+  if (c->logn == 14 && !c->sw.no_mixed) (void)key_twin(c, key);  // the fp64 limbs of a mixed chain go through k_split4_main_fp
   LaneScope scope(c, p.lanes);
   if (scope.fork()) return 1;
   int turn = 0;
@@ -1283,6 +1349,7 @@ static int run_mul_relin(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, i
   const size_t SN = split ? (size_t)c->dc.ps : N;
   const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
+  if (split) (void)key_twin(c, c->d_relin);  // before the lanes fork: they order themselves behind c->stream
   LaneScope scope(c, p.lanes);
   if (scope.fork()) return 1;
   const size_t ctw = 2 * (size_t)nl * N;
@@ -1363,6 +1430,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
   const size_t SN = (splitc || splitb) ? (size_t)c->dc.ps : N;
   const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
+  if (splitc) (void)key_twin(c, key);  // before the lanes fork
   LaneScope scope(c, p.lanes);
   if (scope.fork()) return 1;
   int turn = 0;

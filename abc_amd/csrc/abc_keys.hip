@@ -270,6 +270,7 @@ static int keygen_with(abc_hip_ctx *c, Sampler &pub, Sampler &sec) {
   if (!c->d_pk) ABC_HIP_CHECK(hipMalloc(&c->d_pk, (size_t)2 * K * N * 8));
   if (make_kskey(c, pub, sec, nullptr, c->d_pk, h_a, h_e, d_a, d_e8, d_e, 1)) return 1;
   // relinearisation key: switches s^2 -> s
+  drop_key_twins(c, nullptr);  // every key-switching key is about to be regenerated
   if (!c->d_relin) ABC_HIP_CHECK(hipMalloc(&c->d_relin, c->key_words() * 8));
   hipLaunchKernelGGL(k_dyadic_mul, dim3(grid_for((size_t)K * N, 256)), dim3(256), 0, c->stream, c->dc, c->d_sk, c->d_sk,
                      (size_t)0, d_newkey, kmap, K, (size_t)1);

@@ -30,6 +30,7 @@ SWITCH_SETS = [
     {"ABC_HIP_NO_SPLIT": "1"},
     {"ABC_HIP_NO_SPLIT4": "1"},
     {"ABC_HIP_NO_PACK": "1"},
+    {"ABC_HIP_NO_KEY_TWIN": "1"},
     {"ABC_HIP_NO_BMUL": "1"},
     {"ABC_HIP_NO_LEAN_FRONT": "1"},
     {"ABC_HIP_NO_FUSED": "1"},

@@ -19,6 +19,7 @@ VARIANTS = {
     "fp64_fat_front": {"ABC_HIP_NO_LEAN_FRONT": "1"},  # the 139 KiB tensor / operand kernel even for small batches
     "fp64_unpacked": {"ABC_HIP_NO_PACK": "1"},  # half-done limbs as raw doubles (default: 5 / 6 bytes for primes <= 40 / 48 bits)
     "fp64_unpacked_fat_front": {"ABC_HIP_NO_PACK": "1", "ABC_HIP_NO_LEAN_FRONT": "1"},
+    "fp64_u64_keys": {"ABC_HIP_NO_KEY_TWIN": "1"},  # key words converted per use instead of read from the key's fp64 twin
     "fp64_split3_main": {"ABC_HIP_NO_SPLIT4": "1"},  # previous generation of the last step (also what six and seven data limbs take)
     "generic": {"ABC_HIP_NO_FUSED": "1"},
     "no_galois_fusion_sync_alloc": {"ABC_HIP_NO_GALOIS_FUSION": "1", "ABC_HIP_SYNC_ALLOC": "1"},
