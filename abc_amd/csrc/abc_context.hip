@@ -37,6 +37,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_pack = env_on("ABC_HIP_NO_PACK");
   s.no_key_twin = env_on("ABC_HIP_NO_KEY_TWIN");
   s.no_bmul = env_on("ABC_HIP_NO_BMUL");
+  s.no_special8x2 = env_on("ABC_HIP_NO_SPECIAL8X2");
   s.no_bmul_mid = env_on("ABC_HIP_NO_BMUL_MID");
   s.no_finish_lds = env_on("ABC_HIP_NO_FINISH_LDS");
   s.no_lean_front = env_on("ABC_HIP_NO_LEAN_FRONT");

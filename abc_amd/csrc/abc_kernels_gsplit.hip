@@ -333,6 +333,74 @@ __global__ __launch_bounds__(NL * 64, (ALL && NL == 8) ? 4 : 1) void k_gsplit_sp
   }
 }
 
+// ---- G2a for eight digits in TWO rounds of four (BFV, ALL key primes): 256 threads, four transform buffers (35 KiB: four workgroups
+// per CU where the 512-thread form above has two), the sums carried in registers across the rounds, two coefficient pairs per thread.
+// Same arithmetic, same buffers as k_gsplit_special<LOGN, 8, true>.
+template <int LOGN>
+__global__ __launch_bounds__(256, 4) void k_bsplit_special8x2(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
+                                                               double *__restrict__ tsp_half, int cc) {
+  constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, nl = 8;
+  __shared__ double dyn[4 * lds_words(10)];
+  const int W = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const unsigned sx = blockIdx.x & 7, rest = blockIdx.x >> 3;  // workgroup order as above: a key slice stays with one XCD
+  const unsigned ctu = rest % (unsigned)cc, slice = (rest / (unsigned)cc) * 8 + sx;
+  const int blk = (int)(slice & (NB - 1));
+  const int I = (int)(slice >> LOGNB);
+  const size_t ct = (size_t)ctu;
+  const size_t N = (size_t)1 << LOGN, base = (size_t)blk << 10, PS = (size_t)c.ps;
+  const int ki = (I == nl) ? c.K - 1 : I;
+  const Mod m = mod_at(c, ki);
+  const FpTable t = fp_table(c, ki);
+  const double q = m.qd, qinv = m.qinv;
+  double s0[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, s1[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  double *buf = dyn + W * lds_words(10);
+#pragma nounroll
+  for (int r = 0; r < 2; r++) {
+    const int J = 4 * r + W;
+    const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * PS + base;
+    double xin[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) xin[k] = src[(k << 6) + lane];
+    if (r) __syncthreads();  // round 0's buffers have been consumed
+    ntt_fwd_block_a<10, FpArith>(
+        buf, [&](int s, int) { return fp_centre(xin[s], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, LOGNB, blk,
+        lane);
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < 2; pp++) {
+      const int e = 2 * (int)threadIdx.x + 512 * pp;
+#pragma unroll
+      for (int Jx = 0; Jx < 4; Jx++) {
+        const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
+        const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)(4 * r + Jx) * 2 + 0) * c.K + ki) * N + base + e);
+        const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)(4 * r + Jx) * 2 + 1) * c.K + ki) * N + base + e);
+        s0[pp][0] += g_mulmod(v.x, fp_from_u64(k0.x), q, qinv);
+        s0[pp][1] += g_mulmod(v.y, fp_from_u64(k0.y), q, qinv);
+        s1[pp][0] += g_mulmod(v.x, fp_from_u64(k1.x), q, qinv);
+        s1[pp][1] += g_mulmod(v.y, fp_from_u64(k1.y), q, qinv);
+      }
+    }
+  }
+  // park the centred sums in buffers 0 and 1: a thread rewrites only words it alone read in the last round
+#pragma unroll
+  for (int pp = 0; pp < 2; pp++) {
+    const int e = 2 * (int)threadIdx.x + 512 * pp;
+    f64x2 rr;
+    rr.x = fp_centre(s0[pp][0], q, qinv); rr.y = fp_centre(s0[pp][1], q, qinv);
+    *reinterpret_cast<f64x2 *>(dyn + lds_pad(e)) = rr;
+    rr.x = fp_centre(s1[pp][0], q, qinv); rr.y = fp_centre(s1[pp][1], q, qinv);
+    *reinterpret_cast<f64x2 *>(dyn + lds_words(10) + lds_pad(e)) = rr;
+  }
+  __syncthreads();
+  if (W < 2) {
+    double *b2 = dyn + W * lds_words(10);
+    double *__restrict__ dst = tsp_half + ((ct * (nl + 1) + I) * 2 + W) * PS + base;
+    ntt_inv_block_a<10, FpArith>(
+        b2, [&](int, int i) { return b2[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, LOGNB, blk, lane);
+  }
+}
+
 // ---- G2b: special-prime limb back to coefficients (cross pass), + q_sp/2; forward cross pass of (t mod q_j + fix) per data prime ----
 template <int LOGN>
 __global__ __launch_bounds__(256) void k_gsplit_pass(DevCtx c, const double *__restrict__ tsp_half, double *__restrict__ tpart, int nl) {
@@ -813,6 +881,9 @@ int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
                   size_t addend_stride, int add_c1, u64 *out) {
   const dim3 g((unsigned)(cc * (nl + 1) * 16));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
+  if (nl == 8 && !c->sw.no_special8x2) {  // two rounds of four digits, four workgroups per CU: +2 % multiply, +5 % rotate
+    hipLaunchKernelGGL((k_bsplit_special8x2<14>), g, dim3(256), 0, st, c->dc, part, key, half, (int)cc);
+  } else
 #define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<14, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
   switch (nl) {
     case 1: ABC_BSP(1); break;
@@ -1091,6 +1162,9 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
     hipLaunchKernelGGL((k_bsplit_pass0_lds<LOGN>), dim3((unsigned)(cc * nl * 32)), dim3(256), 0, st, c->dc, target, target_stride, part, nl);
   const dim3 g((unsigned)(cc * (nl + 1) * NB));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
+  if (nl == 8 && !c->sw.no_special8x2) {
+    hipLaunchKernelGGL((k_bsplit_special8x2<LOGN>), g, dim3(256), 0, st, c->dc, part, key, half, (int)cc);
+  } else
 #define ABC_BSPB(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
   switch (nl) {
     case 1: ABC_BSPB(1); break;
