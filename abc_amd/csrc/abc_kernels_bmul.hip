@@ -174,7 +174,7 @@ __global__ __launch_bounds__(4 * ((1 << LB) / 16)) void k_bmul_mid(DevCtx c, con
   double *buf = dyn + G * LW;
   {  // group G: forward tail of operand polynomial G (a0, a1, b0, b1), centred result parked in LDS
     const double *__restrict__ src = hA + ((ct * 4 + G) * nlm + l) * N + base;
-    ntt_fwd_block_a<LB, FpArith>(
+    ntt_fwd_block_a<LB, FpTail>(
         buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = fp_centre(v, q, qinv); }, t,
         m, LOGNB, blk, gt);
   }

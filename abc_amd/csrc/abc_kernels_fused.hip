@@ -704,7 +704,7 @@ __global__ __launch_bounds__(NL ? NL * 64 : 768) void k_split_special_fp(DevCtx 
   {
     double *buf = dyn + J * lds_words(10);
     const double *__restrict__ src = part + ((ct * (nl + 1) + nl) * nl + J) * (size_t)c.ps + base;
-    ntt_fwd_block_a<10, FpArith>(
+    ntt_fwd_block_a<10, FpTail>(
         buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk,
         lane);
   }
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_split4_main_fp(DevCtx 
 #pragma unroll
       for (int r = 0; r < 16; r++) xin[r] = fp_centre(xin[r], q, qinv);
     }
-    ntt_fwd_tail1024_pairs<FpArith>(buf, xin, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk, lane, ltw);
+    ntt_fwd_tail1024_pairs<FpTail>(buf, xin, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, 4, blk, lane, ltw);
   }
   __syncthreads();
   const double *tt0 = dyn + (nl - 1) * lds_words(10), *tt1 = dyn + nl * lds_words(10);

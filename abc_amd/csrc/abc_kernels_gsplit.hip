@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NL * 64, (ALL && NL == 8) ? 4 : 1) void k_gsplit_sp
   {
     double *buf = dyn + J * lds_words(10);
     const double *__restrict__ src = part + ((ct * (nl + 1) + I) * nl + J) * PS + base;
-    ntt_fwd_block_a<10, FpArith>(
+    ntt_fwd_block_a<10, FpTail>(
         buf, [&](int, int i) { return fp_centre(src[i], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, LOGNB,
         blk, lane);
   }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 4) void k_bsplit_special8x2(DevCtx c, const do
 #pragma unroll
     for (int k = 0; k < 16; k++) xin[k] = src[(k << 6) + lane];
     if (r) __syncthreads();  // round 0's buffers have been consumed
-    ntt_fwd_block_a<10, FpArith>(
+    ntt_fwd_block_a<10, FpTail>(
         buf, [&](int s, int) { return fp_centre(xin[s], q, qinv); }, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, LOGNB, blk,
         lane);
     __syncthreads();
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512, NL <= 4 ? 4 : 2) void k_gsplit_main(DevCtx c, 
     double *buf = dyn + W * lds_words(10);
 #pragma unroll
     for (int r = 0; r < 16; r++) xin[r] = fp_centre(xin[r], q, qinv);
-    ntt_fwd_tail1024_pairs<FpArith>(buf, xin, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, LOGNB, blk, lane, ltw);
+    ntt_fwd_tail1024_pairs<FpTail>(buf, xin, [&](int, int i, double v) { buf[lds_pad(i)] = v; }, t, m, LOGNB, blk, lane, ltw);
   }
   __syncthreads();
   const double *tt0 = dyn + (nl - 1) * lds_words(10), *tt1 = dyn + nl * lds_words(10);

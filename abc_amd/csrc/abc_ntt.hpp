@@ -207,6 +207,18 @@ struct FpArith {
   }
 };
 
+// Forward BLOCK TAILS (at most 12 stages) that start from a CENTRED input, |x| <= q/2: the per-stage bound Y -> Y (1 + q 2^-53) + q/2
+// gives, from 0.5 q,  1.06, 1.70, 2.41, 3.21, 4.11, 5.12, 6.26, 7.55 q after eight stages of a 50-bit prime (2^53 = 8 q * 2^50 / q:
+// the ninth would pass it) and 7.6 q after ten, 9.6 q after twelve stages of a 49-bit one (limit 16 q).  So a tail needs ONE
+// re-centring for 50-bit primes -- before pass 2, which every schedule reaches after at most eight stages (4+4, 3+4) -- and none for
+// 49-bit ones, where FpArith re-centres before every pass (it serves whole 14-stage transforms from canonical inputs too).
+// tests/test_fp64_exactness.py replays both schedules with Python integers.
+struct FpTail : FpArith {
+  template <int PASS> __device__ __forceinline__ static void fwd_begin(E (&x)[16], const K &k) {
+    if (PASS == 2 && k.red && k.q >= 562949953421312.0) centre16(x, k);  // q >= 2^49: a 50-bit prime (workgroup-uniform)
+  }
+};
+
 // ---- one radix-2^R register pass over NG = 16>>R groups -------------------------------------------
 // Forward (CT): stages S..S+R-1 of the block-local transform.
 template <class A, int LB, int S, int R>

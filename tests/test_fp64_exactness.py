@@ -90,13 +90,15 @@ class Model:
 
 
 def _fp_forward(x, q, tables, schedule, recentre):
-    """Cooley-Tukey, natural in -> bit-reversed out, stages grouped into register passes like ntt_fwd_block_a"""
+    """Cooley-Tukey, natural in -> bit-reversed out, stages grouped into register passes like ntt_fwd_block_a.
+    recentre: True (before every pass but the first: FpArith for 49/50-bit primes), False, or the set of passes that start with
+    a re-centring (FpTail: {2} for 50-bit primes, nothing for smaller ones)"""
     n = len(x)
     m = Model(q)
     x = list(x)
     stage = 0
     for pno, r in enumerate(schedule):
-        if pno > 0 and recentre:
+        if (pno in recentre) if isinstance(recentre, (set, frozenset)) else (pno > 0 and recentre):
             x = [m.centre(v) for v in x]
         for _ in range(r):
             half = n >> (stage + 1)
@@ -138,6 +140,46 @@ def test_fp64_forward_transform_is_exact_and_matches_oracle(bits, red):
         assert got == [int(v) for v in want], name
         # stated bounds: 8q for the re-centring primes, 2^52 for the others
         assert peak < (8 * q if red else 1 << 52), (name, peak / q)
+
+
+@pytest.mark.parametrize("bits,schedule,recentre", [
+    (50, (4, 4, 2), {2}), (50, (3, 4, 3), {2}), (49, (4, 4, 2), set()), (49, (3, 4, 3), set()),
+    (50, (4, 4, 2, 2), {2}), (49, (4, 4, 2, 2), set()),
+])
+def test_fp64_block_tail_policy_from_centred_inputs(bits, schedule, recentre):
+    """FpTail (abc_ntt.hpp): a forward block tail of ten (1024 points) or twelve (4096 points) stages that starts from CENTRED
+    values re-centres once for a 50-bit prime (before pass 2) and never for a 49-bit one -- every step exact, every magnitude
+    below 2^53, residues equal to the oracle's transform."""
+    from oracle import oracle_py as om
+    n = 1 << sum(schedule)
+    primes = om.create_primes(n, [bits, 40])
+    q = primes[0]
+    o = om.Oracle(om.CKKS, n, primes)
+    tables = _tables(n, q)
+    rng = np.random.default_rng(5)
+    half = (q - 1) // 2
+    inputs = {  # centred representatives, |x| <= q/2
+        "all +q/2": [half] * n,
+        "all -q/2": [-half] * n,
+        "alternating": [half if i & 1 else -half for i in range(n)],
+        "blocks": [half if (i >> 3) & 1 else -half for i in range(n)],
+        "random": [int(v) - half for v in rng.integers(0, q, size=n, dtype=np.uint64)],
+    }
+    for name, x in inputs.items():
+        got, peak = _fp_forward(x, q, tables, schedule, recentre)
+        want = o.ntt(0, np.array([v % q for v in x], dtype=np.uint64))
+        assert got == [int(v) for v in want], name
+        assert peak < LIMIT, (name, peak / q)
+    # the bound the policy rests on: eight stages of a 50-bit prime from q/2 stay below 2^53, a ninth would not;
+    # twelve stages of a 49-bit prime stay below it with room to spare
+    def grow(y, qq, stages):
+        for _ in range(stages):
+            y = y * (1.0 + qq * 2.0 ** -53) + qq / 2.0
+        return y
+    q50 = float((1 << 50) - 1)
+    assert grow(q50 / 2, q50, 8) < 2.0 ** 53 < grow(q50 / 2, q50, 9)
+    q49 = float((1 << 49) - 1)
+    assert grow(q49 / 2, q49, 12) < 2.0 ** 52.5
 
 
 def test_recentring_is_necessary_for_50_bit_primes():
