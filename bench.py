@@ -280,14 +280,14 @@ def run_rank(args):
                 a6, b6 = rand_ct(p60, B60), rand_ct(p60, B60)
                 o6 = torch.empty_like(a6)
             p6 = [C.c_void_p(t.data_ptr()) for t in (a6, b6, o6)]
-            for _ in range(2):
+            for _ in range(3):
                 g60.op("mul_relin", *p6, L, C.c_size_t(B60))
             torch.cuda.synchronize()
             t6 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(10):
                 g60.op("mul_relin", *p6, L, C.c_size_t(B60))
             torch.cuda.synchronize()
-            v60 = 5 * B60 / (time.perf_counter() - t6)
+            v60 = 10 * B60 / (time.perf_counter() - t6)
             line["value_60bit_primes"] = v60
             line["value_60bit_primes_detail"] = {"value": v60, "unit": "mul+relin/s", "frac": v60 * ALGO_BYTES / (HBM_PEAK_GBS * 1e9),
                                                  "workload": "CKKS N=16384 {60,40,40,40 | 60}: integer kernels for the 60-bit primes, batch %d" % B60}
@@ -313,17 +313,20 @@ def run_rank(args):
                 ab, bb = rand_bfv(), rand_bfv()
                 ob = torch.empty_like(ab)
             pb = [C.c_void_p(t.data_ptr()) for t in (ab, bb, ob)]
-            for _ in range(2):
+            for _ in range(3):
                 gb.op("mul_relin", *pb, Lb, C.c_size_t(Bb))
             torch.cuda.synchronize()
+            gb.timer_start()  # HIP events on the launch stream, as for the headline
             tb = time.perf_counter()
-            for _ in range(5):
+            for _ in range(10):
                 gb.op("mul_relin", *pb, Lb, C.c_size_t(Bb))
+            ev_b = gb.timer_stop()
             torch.cuda.synchronize()
-            vb = 5 * Bb / (time.perf_counter() - tb)
+            wall_b = time.perf_counter() - tb
+            vb = 10 * Bb / wall_b
             algo_b = 8 * nb * (6 * Lb + 2 * Lb * (Lb + 1))  # SURVEY.md section 8d's formula at L = 8: 25.2 MB
             line["value_bfv_default_ring"] = {"value": vb, "unit": "mul+relin/s", "frac": vb * algo_b / (HBM_PEAK_GBS * 1e9),
-                                              "algorithmic_bytes_per_unit": algo_b,
+                                              "algorithmic_bytes_per_unit": algo_b, "launch_ms": ev_b / 10, "steps": 10, "warmup": 3,
                                               "workload": "BFV BFVDefault(16384) (8 data limbs + special), t = Batching(16384, 20), batch 256"}
             ob_ = om.Oracle(om.BFV, nb, list(gb.primes), gb.t)
             ob_.keygen(0xABC00001)
