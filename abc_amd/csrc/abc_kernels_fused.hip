@@ -6,19 +6,16 @@
 //   SealCiphertext::multiply / multiplyInplace = Evaluator::multiply + relinearize_inplace
 //       (src/runtime/SealCiphertext.cpp:102-107,121-124)                     -> ckks_mul_relin_fused, keyswitch_fused
 //   SealCiphertext::rotateRows / rotateRowsInplace = Evaluator::rotate_rows    (:52-61) -> keyswitch_fused
-// Three generations of the same launch sequence live here; the dispatcher (keyswitch_stage / run_mul_relin /
-// run_keyswitch) takes the first one the context's primes and ring size allow, and tests/test_gpu_paths.py holds all of
-// them bit-identical to the oracle:
-//   split fp64  (N = 2^14, every key prime < 2^50; the headline configuration)
-//       K1s tensor_pass0 / operand_pass0 : tensor product + inverse transform of c2_j in LDS, then the first radix-16
-//                                          register pass of the forward transforms modulo the other key primes;
-//                                          half-done limbs to scratch as raw doubles
-//       K2s tailmac_coop                 : wavefront J finishes limb (I, J) on a 1024-point block and multiplies into
-//                                          the key; LDS accumulators
-//       K2c special_intt_fp, K3 moddown_fp / moddown_bfv_fp
-//   un-split fp64 (N < 2^14, every key prime < 2^50)
-//       K1 tensor_decomp_fp (or tensor_intt_fp / operand_intt_fp + decomp_ntt_fp), K2b mac, K2c, K3
-//   integer     (any prime up to 61 bits)
+// Three launch sequences live here; the dispatcher (run_mul_relin / run_keyswitch / keyswitch_stage) takes the first one the
+// context's primes and ring size allow, and tests/test_gpu_paths.py holds all of them bit-identical to the oracle:
+//   split fp64  (N = 2^14, every key prime < 2^50; the headline configuration; sequence described above k_split2_tensor_pass0_fp)
+//       K1  k_split2_tensor_pass0_fp / k_fused_operand_pass0_fp : tensor product or operand, inverse transform of limb j in LDS,
+//                                          first radix-16 register pass of the forward transforms modulo the other key primes;
+//                                          half-done limbs to scratch, packed (abc_ntt.hpp) or as raw doubles
+//       K2a k_split_special_fp, K2b k_split3_pass_fp, K2c k_split4_main_fp (k_split3_main_fp for six and seven limbs)
+//   LDS-resident fp64 (N < 2^14, or ABC_HIP_NO_SPLIT; every key prime < 2^50)
+//       K1 tensor_decomp_fp (operand_intt_fp + decomp_ntt_fp for a key switch), K2b mac, K2c special_intt_fp, K3 moddown_fp / _bfv_fp
+//   LDS-resident integer (any prime up to 61 bits)
 //       K1  tensor_intt : c0 = a0b0, c1 = a0b1 + a1b0 to scratch (so `out` may alias an operand); c2 = a1b1 kept in
 //                         NTT form and, through an in-LDS inverse transform, in coefficient form
 //       K2a decomp_ntt  : workgroup (ct, key prime I, limb J) reduces operand limb J modulo key prime I and
@@ -28,6 +25,8 @@
 //       K3  moddown     : workgroup (ct, comp, j): CKKS: reduce the special-prime polynomial modulo q_j, transform
 //                         it, subtract, scale by q_sp^-1, add c0 / c1.  BFV: inverse-transform the accumulated limb,
 //                         then the same subtract / scale / add in coefficient form
+// (chains that mix wide and fp64-capable primes: abc_kernels_isplit.hip; N = 2^15: abc_kernels_gsplit.hip; BFV multiply:
+// abc_kernels_bmul.hip)
 // Algorithmic HBM bytes per multiply: 8N(6L + 2L(L+1)); measured: DESIGN.md section 4.
 #include <type_traits>
 
