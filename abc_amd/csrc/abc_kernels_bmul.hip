@@ -154,8 +154,8 @@ __global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__re
 // LB: block size of the tails (10 at N = 2^14: one wavefront per operand polynomial, 256 threads, 35 KiB; 12 at N = 2^15 / 2^16:
 // 256 threads per operand polynomial, 1024 threads, 139 KiB -- one workgroup per CU, but its 187 limb transfers per limb-block
 // shrink to 7: the separate forward-tail kernel wrote and the tensor kernel re-read every operand limb).  Groups of T = 2^LB / 16
-// threads run the block transforms of abc_ntt.hpp side by side; for LB > 10 those contain workgroup barriers, so all four groups
-// execute every transform call (the fourth group's inverse pass is a repeat of component 2 that stores nothing).
+// threads run the block transforms of abc_ntt.hpp side by side; for LB > 10 those contain one workgroup barrier each, which the
+// fourth group -- it has no product component to transform back -- joins without doing the work.
 template <int LOGN, int LB>
 __global__ __launch_bounds__(4 * ((1 << LB) / 16)) void k_bmul_mid(DevCtx c, const double *__restrict__ hA, double *__restrict__ hD, int nlm, int L) {
   constexpr int LOGNB = LOGN - LB, T = (1 << LB) / 16, LW = lds_words(LB);
@@ -195,18 +195,13 @@ __global__ __launch_bounds__(4 * ((1 << LB) / 16)) void k_bmul_mid(DevCtx c, con
     *reinterpret_cast<f64x2 *>(p2) = d;
   }
   __syncthreads();
-  if (LB > 10 || G < 3) {  // inverse tail of product component G; N^-1 belongs to the cross pass (M3)
-    const bool live = G < 3;
-    const int comp = live ? G : 2;
-    // the fourth group of a barrier-synchronised transform works on a private copy of component 2 (its own buffer) and stores nothing
-    if (LB > 10 && !live) {
-      for (int i = gt; i < (1 << LB); i += T) buf[lds_pad(i)] = dyn[2 * LW + lds_pad(i)];
-    }
-    if (LB > 10) __syncthreads();
-    double *tb = live ? dyn + comp * LW : buf;
-    double *__restrict__ dst = hD + ((ct * 3 + comp) * nlm + l) * N + base;
+  if (G < 3) {  // inverse tail of product component G; N^-1 belongs to the cross pass (M3)
+    double *tb = dyn + G * LW;
+    double *__restrict__ dst = hD + ((ct * 3 + G) * nlm + l) * N + base;
     ntt_inv_block_a<LB, FpArith>(
-        tb, [&](int, int i) { return tb[lds_pad(i)]; }, [&](int, int i, double v) { if (live) dst[i] = v; }, t, m, LOGNB, blk, gt);
+        tb, [&](int, int i) { return tb[lds_pad(i)]; }, [&](int, int i, double v) { dst[i] = v; }, t, m, LOGNB, blk, gt);
+  } else if (LB > 10) {
+    block_sync_lds();  // the ONE workgroup barrier inside ntt_inv_block_a<LB > 10> (before its last pass): the fourth group only keeps count
   }
 }
 
