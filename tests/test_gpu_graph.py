@@ -69,3 +69,39 @@ def test_capture_refuses_to_grow_scratch(capi):
         g.graph_end()
     except capi.AbcHipError:
         pass
+
+
+def test_captured_circuit_on_the_default_ring_with_lanes(oracle_mod, capi):
+    """BFVDefault(16384), a batch large enough for two internal lanes: the split BEHZ multiply (abc_kernels_bmul.hip) and the key
+    switch record into a graph with their lane fork / join events; the replay must equal eager execution and the oracle."""
+    n = 16384
+    o = oracle_mod.Oracle.bfv_default(n)
+    o.keygen(78)
+    g = capi.Context.bfv_default(n)
+    g.keygen(78)
+    a = o.encrypt(o.encode(oracle_mod.expand_vector([3, 3, 1, 4, 5, 9], n)), 1)
+    b = o.encrypt(o.encode(oracle_mod.expand_vector([0, 1, 2, 1, 10, 21], n)), 2)
+    B = 12
+    batch_a = np.stack([a if i % 2 else b for i in range(B)])
+    batch_b = np.stack([b if i % 3 else a for i in range(B)])
+    da, db = g.upload(batch_a), g.upload(batch_b)
+    t1, out = g.alloc(batch_a.nbytes), g.alloc(batch_a.nbytes)
+    L, cb = g.L, C.c_size_t(B)
+
+    def circuit():
+        g.op("mul_relin", da.ptr, db.ptr, t1.ptr, L, cb)
+        g.op("rotate", t1.ptr, out.ptr, L, 3, cb)
+
+    circuit()
+    g.sync()
+    eager = g.download(out, batch_a.shape)
+    for i in (0, 1, 5, B - 1):
+        assert np.array_equal(eager[i], o.rotate(o.mul_relin(batch_a[i], batch_b[i]), 3)), i
+    g.graph_begin()
+    circuit()
+    graph = g.graph_end()
+    g.op("negate", out.ptr, out.ptr, 2, L, cb)
+    g.graph_launch(graph)
+    g.sync()
+    assert np.array_equal(g.download(out, batch_a.shape), eager)
+    g.graph_destroy(graph)
