@@ -9,7 +9,7 @@
 //                           inverse transform in 8.5 KiB of LDS, inverse twiddles of the block in a shared LDS table -> hinv
 //   G1b k_gsplit_cross      (registers only): inverse cross pass, N^-1, canonical coefficient; per other key prime the forward
 //                           cross pass -> half-done decomposition limbs `part`
-//   G2a k_gsplit_special, G2b k_gsplit_pass, G2c k_gsplit_main: as k_split2_tailmac_fp (special prime) / k_split3_pass_fp /
+//   G2a k_gsplit_special, G2b k_gsplit_pass, G2c k_gsplit_main: as k_split_special_fp (special prime) / k_split3_pass_fp /
 //                           k_split4_main_fp of abc_kernels_fused.hip with NB blocks and radix-NB cross passes
 // Same arithmetic as the N = 2^14 kernels (exact fp64 residues, primes < 2^50), bit-identical results
 // (tests/test_gpu_configs.py, tests/test_gpu_paths.py).  Replaces, for N = 2^15, the generic sequence (expand / strided
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__
   }
 }
 
-// ---- G2a: special prime (cf. k_split2_tailmac_fp, only_special) ----
+// ---- G2a: special prime (cf. k_split_special_fp) ----
 // ALL = false: the special prime only (CKKS: the data primes go through k_gsplit_main); output [ct][comp] limbs.
 // ALL = true (BFV, operand in coefficient form: no diagonal term, no NTT-form output): every key prime I = 0..nl, grid
 //   (ct, I, block); the inverse-transform tails of BOTH the special limb and the accumulated data limbs; output

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_igsplit_cross(DevCtx c, const u64 *__re
   }
 }
 
-// K2a: the special prime's inner product and the block-local stages of its inverse transform (cf. k_split2_tailmac_fp)
+// K2a: the special prime's inner product and the block-local stages of its inverse transform (cf. k_split_special_fp)
 template <bool GUARD, int NL, int LOGN>
 __global__ __launch_bounds__(NL * 64) void k_isplit_special(DevCtx c, const u64 *__restrict__ part, const u64 *__restrict__ key,
                                                             u64 *__restrict__ tsp_half) {

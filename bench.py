@@ -251,7 +251,7 @@ def run_rank(args):
                          # SURVEY.md section 8d's second accounting: relin key counted as cache-resident across the batch (3 MiB / op)
                          "frac_key_resident": achieved / HBM_PEAK_GBS * ALGO_BYTES_KEY_RESIDENT / ALGO_BYTES,
                          "algorithmic_bytes_per_unit": ALGO_BYTES, "algorithmic_bytes_per_unit_key_resident": ALGO_BYTES_KEY_RESIDENT,
-                         "kernel": "abc_hip_mul_relin (rank 0's launch) = k_split2_tensor_pass0_fp + k_split2_tailmac_fp (special prime) + "
+                         "kernel": "abc_hip_mul_relin (rank 0's launch) = k_split2_tensor_pass0_fp + k_split_special_fp (special prime) + "
                                    "k_split3_pass_fp + k_split4_main_fp (dominant), DESIGN.md section 4",
                          "algorithmic_bytes_per_launch": ALGO_BYTES * B, "launch_ms": launch_ms},
         }

@@ -219,3 +219,27 @@ def test_fp64_inverse_butterfly_bounds():
             yv = q / 2 + diff * q * 2.0 ** -53    # |(a - b) w| after the lazy product
             y = max(2 * y, yv)                    # |a + b|
         assert y <= 8 * q
+
+
+def test_packed_half_done_limb_encoding_round_trips():
+    """abc_ntt.hpp, "packed half-done limbs": a centred residue c (|c| <= q/2) is stored as the low dword of bits(c + 1.5 * 2^52) plus the
+    next byte (primes of at most 40 bits) or half-word (at most 48 bits); the reader rebuilds bits(...) from the SIGN-EXTENDED high part
+    and subtracts the constant.  Replayed here with numpy's IEEE doubles on the ends of the range and random values."""
+    magic = np.float64(6755399441055744.0)  # 2^52 + 2^51
+    rng = np.random.default_rng(17)
+    for bits, hi_bits in ((40, 8), (36, 8), (48, 16), (41, 16)):
+        half = (1 << (bits - 1)) - 1
+        vals = np.concatenate([np.array([0, 1, -1, half, -half, half - 1, -(half - 1), 255, -256, 1 << 32, -(1 << 32), (1 << 32) - 1],
+                                        dtype=np.int64),
+                               rng.integers(-half, half + 1, size=20000, dtype=np.int64)])
+        c = vals.astype(np.float64)
+        assert np.array_equal(c.astype(np.int64), vals)            # exactly representable
+        b = (c + magic).view(np.uint64)
+        lo = (b & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi = ((b >> np.uint64(32)) & np.uint64((1 << hi_bits) - 1)).astype(np.uint32)
+        # reader: sign-extend the stored high part, add it to the high word of the constant's bit pattern
+        hs = hi.astype(np.int64)
+        hs = np.where(hs >= (1 << (hi_bits - 1)), hs - (1 << hi_bits), hs)
+        top = (np.int64(0x43380000) + hs).astype(np.uint64)
+        rebuilt = ((top << np.uint64(32)) | lo.astype(np.uint64)).view(np.float64) - magic
+        assert np.array_equal(rebuilt, c), bits
