@@ -177,6 +177,195 @@ int launch_ks_finish(abc_hip_ctx *c, const u64 *prodD, const u64 *tmod, u64 *out
   return 0;
 }
 
+// ---- N = 2^15 / 2^16, integer arithmetic (a key prime above 2^50: config 5's 55-bit chain): decomposition and inner product
+// in two kernels instead of five.  The generic sequence writes every digit once per key prime (k_ks_expand), carries those
+// nl (nl + 1) limbs through the strided pass and the block transforms (two round trips) and reads them again in k_ks_inner:
+// five transfers of nl (nl + 1) limbs.  Here:
+//   k_iks_pass0   (ct, digit J, key prime I, 256 positions): digit J read as it lies, reduced modulo q_I, strided first
+//                 stages -> half-done limb (ct, J, I)                                        [one write]
+//   k_iks_special (ct, key prime I, 4096-point block b): per digit J the block stages in LDS, the transform's outputs go
+//                 straight from registers into the two inner products with the key (same register layout for every J and
+//                 for the inverse block transform that follows), then the inverse block stages of both sums -> prodD /
+//                 prodS half-done (the strided last stages, q_sp rounding and the subtraction stay with the generic
+//                 kernels)                                                                    [one read, 2 / nl of a write]
+// Inner products: canonical operands, one Barrett product per term (a 128-bit accumulator per value would cost 128 VGPRs).
+template <int R>
+__global__ __launch_bounds__(256) void k_iks_pass0(DevCtx c, const u64 *__restrict__ tcoef, size_t tstride, u64 *__restrict__ dec, int nl) {
+  const int G = c.n >> R;
+  const int per = G / 256;
+  const size_t limb = blockIdx.x / per;  // (ct * nl + J) * (nl + 1) + I
+  const int p = (blockIdx.x % per) * 256 + threadIdx.x;
+  const int I = (int)(limb % (size_t)(nl + 1));
+  const size_t cj = limb / (size_t)(nl + 1);
+  const int J = (int)(cj % (size_t)nl);
+  const size_t ct = cj / (size_t)nl;
+  const int ki = (I == nl) ? c.K - 1 : I;
+  const Mod m = c.mods[ki];
+  const NttTable t = ntt_table(c, ki);
+  const u64 *__restrict__ src = tcoef + ct * tstride + (size_t)J * c.n + p;
+  u64 x[1 << R];
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) x[k] = src[(size_t)k * G];
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) x[k] = reduce64(x[k], m);
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    const int half = 1 << (R - 1 - u);
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      if (k & half) continue;
+      const u64x2 tp = tw_load(t.tw + (1 << u) + (k >> (R - u)));
+      const u64 a = csub(x[k], m.two_q);
+      const u64 v = mul_shoup_lazy(x[k | half], tp.x, tp.y, m.q);
+      x[k] = a + v;
+      x[k | half] = a + m.two_q - v;
+    }
+  }
+  u64 *__restrict__ dst = dec + limb * (size_t)c.n + p;
+#pragma unroll
+  for (int k = 0; k < (1 << R); k++) dst[(size_t)k * G] = x[k];  // lazy [0, 4q): the block stages are guarded
+}
+
+// Shoup quotients of a key-switching key, floor(w 2^64 / q) per word, same layout: with them a term of the inner product is one
+// lazy Shoup product of ANY 64-bit transform output (no canonicalisation, no 128-bit product, no Barrett): built on first use,
+// dropped with the key's other mirror (drop_key_twins).
+__global__ __launch_bounds__(256) void k_key_to_shoup(DevCtx c, const u64 *__restrict__ key, u64 *__restrict__ ks, size_t words) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
+    const int kp = (int)((i >> c.logn) % (size_t)c.K);
+    const u64 q = c.mods[kp].q;
+    u64 r = key[i], quo = 0;  // r < q < 2^61: schoolbook division of r 2^64 by q, one quotient bit per step
+    for (int bit = 0; bit < 64; bit++) {
+      r <<= 1;
+      const bool ge = r >= q;
+      r -= ge ? q : 0;
+      quo = (quo << 1) | (ge ? 1u : 0u);
+    }
+    ks[i] = quo;
+  }
+}
+static const u64 *key_shoup(abc_hip_ctx *c, const u64 *key) {
+  if (c->sw.no_key_twin || !key) return nullptr;
+  auto it = c->key_shoups.find(key);
+  if (it != c->key_shoups.end()) return it->second;
+  if (c->capture_active) return nullptr;  // built by the eager pass that precedes every recording
+  u64 *d = nullptr;
+  const size_t words = c->key_words();
+  if (hipMalloc(&d, words * 8) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  hipLaunchKernelGGL(k_key_to_shoup, dim3(grid_for(words, 256)), dim3(256), 0, c->stream, c->dc, key, d, words);
+  c->key_shoups[key] = d;
+  return d;
+}
+
+// INV_D: the data limbs' sums go back to coefficients too (BFV); CKKS keeps them in NTT form.  SHOUP: `keys` = the key's Shoup
+// quotients; sums of lazy products (< 2q each) stay below 2^64 for up to 16 digits of a 59-bit prime, wider primes fold after
+// every term.
+template <int LB, bool INV_D, bool SHOUP, bool GUARD>
+__global__ __launch_bounds__((1 << LB) / 16, 3) void k_iks_special(DevCtx c, const u64 *__restrict__ dec, const u64 *__restrict__ key,
+                                                                    const u64 *__restrict__ keys, u64 *__restrict__ prodD,
+                                                                    u64 *__restrict__ prodS, int nl, int S0, unsigned cc) {
+  __shared__ u64 lds[lds_words(LB)];
+  // Every workgroup of a (key prime, block) pair reads the same 2 nl (x 2 with quotients) key blocks: ciphertext index fastest,
+  // and -- consecutive workgroup ids go to consecutive XCDs -- the id is remapped so that one XCD's L2 sees the whole run
+  // of ciphertexts of a pair (the grid is a multiple of 8: 2^S0 blocks per limb).
+  const unsigned per_xcd = gridDim.x >> 3;
+  const unsigned wid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const size_t ct = wid % cc;
+  const unsigned pair = wid / cc;
+  const int b = (int)(pair & ((1u << S0) - 1));
+  const int I = (int)(pair >> S0);
+  const int ki = (I == nl) ? c.K - 1 : I;
+  const Mod m = c.mods[ki];
+  const NttTable t = ntt_table(c, ki);
+  const size_t N = (size_t)c.n, off = (size_t)b << LB;
+  const bool fold = m.bits > 59;
+  u64 acc0[16], acc1[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc0[r] = acc1[r] = 0;
+#pragma nounroll
+  for (int J = 0; J < nl; J++) {
+    const u64 *__restrict__ in = dec + ((ct * nl + J) * (size_t)(nl + 1) + I) * N + off;
+    const size_t kw = (((size_t)J * 2) * c.K + ki) * N + off, kw1 = kw + (size_t)c.K * N;
+    ntt_fwd_block<LB, GUARD>(
+        lds, [&](int, int i) { return in[i]; },
+        [&](int r, int i, u64 v) {
+          if (SHOUP) {
+            acc0[r] += mul_shoup_lazy(v, key[kw + i], keys[kw + i], m.q);
+            acc1[r] += mul_shoup_lazy(v, key[kw1 + i], keys[kw1 + i], m.q);
+            if (fold) {
+              acc0[r] = csub(acc0[r], m.two_q);
+              acc1[r] = csub(acc1[r], m.two_q);
+            }
+          } else {
+            const u64 x = canon_fwd<GUARD>(v, m);
+            acc0[r] = add_mod(acc0[r], mul_mod(x, key[kw + i], m), m.q);
+            acc1[r] = add_mod(acc1[r], mul_mod(x, key[kw1 + i], m), m.q);
+          }
+        },
+        t, m, S0, b);
+    block_sync_lds();  // the next transform's first pass rewrites words other wavefronts have just read
+  }
+  if (SHOUP) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      acc0[r] = reduce64(acc0[r], m);
+      acc1[r] = reduce64(acc1[r], m);
+    }
+  }
+  u64 *__restrict__ d0 = (I == nl ? prodS + (ct * 2 + 0) * N : prodD + ((ct * 2 + 0) * nl + I) * N) + off;
+  u64 *__restrict__ d1 = (I == nl ? prodS + (ct * 2 + 1) * N : prodD + ((ct * 2 + 1) * nl + I) * N) + off;
+  if (!INV_D && I != nl) {
+    using P = PassIdx<LB, LB - 2, 2>;  // the forward transform's final register layout
+    int hi[P::NG], lo[P::NG];
+    P::groups((int)threadIdx.x, hi, lo);
+#pragma unroll
+    for (int g = 0; g < P::NG; g++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        d0[P::elem(hi[g], lo[g], k)] = acc0[g * 4 + k];
+        d1[P::elem(hi[g], lo[g], k)] = acc1[g * 4 + k];
+      }
+    return;
+  }
+  ntt_inv_block<LB>(lds, [&](int r, int) { return acc0[r]; }, [&](int, int i, u64 v) { d0[i] = v; }, t, m, S0, b);
+  block_sync_lds();
+  ntt_inv_block<LB>(lds, [&](int r, int) { return acc1[r]; }, [&](int, int i, u64 v) { d1[i] = v; }, t, m, S0, b);
+}
+
+// 1: error; -1: not applicable (the caller takes the generic kernels); 0: prodS holds the special limb's sums half-way back to
+// coefficients (strided stages left), prodD the data limbs' -- likewise for BFV, in NTT form for CKKS
+static int iks_front(abc_hip_ctx *c, const u64 *tc, size_t tcs, const u64 *key, u64 *dec, u64 *prodD, u64 *prodS, int nl, size_t cc) {
+  if ((c->logn != 15 && c->logn != 16) || c->sw.no_iks) return -1;
+  const int S0 = c->logn - big_block_log();
+  if (big_block_log() != 12) return -1;
+  const size_t limbs = cc * nl * (nl + 1);
+  const int G = c->n >> S0;
+  const dim3 g0((unsigned)(limbs * (G / 256)));
+  if (S0 == 3) hipLaunchKernelGGL(k_iks_pass0<3>, g0, dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl);
+  else hipLaunchKernelGGL(k_iks_pass0<4>, g0, dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl);
+  ABC_HIP_CHECK(hipGetLastError());
+  const dim3 g1((unsigned)((cc * (nl + 1)) << S0));
+  const u64 *keys = key_shoup(c, key);
+  const bool ckks = c->scheme == 2;
+  // unguarded butterflies where every key prime leaves the room: [0, 4q) out of the strided pass, + 4q per block stage = 52q < 2^64
+  bool guard = false;
+  for (int j = 0; j < c->K; j++) guard = guard || !unguarded_ok(c->h_mods[j].bits);
+#define ABC_IKS(INV_D, SHOUP)                                                                                                        \
+  do {                                                                                                                               \
+    if (guard)                                                                                                                       \
+      hipLaunchKernelGGL((k_iks_special<12, INV_D, SHOUP, true>), g1, dim3(256), 0, c->stream, c->dc, dec, key, keys, prodD, prodS, \
+                         nl, S0, (unsigned)cc);                                                                                      \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((k_iks_special<12, INV_D, SHOUP, false>), g1, dim3(256), 0, c->stream, c->dc, dec, key, keys, prodD, prodS, \
+                         nl, S0, (unsigned)cc);                                                                                      \
+  } while (0)
+  if (keys) { if (ckks) ABC_IKS(false, true); else ABC_IKS(true, true); }
+  else { if (ckks) ABC_IKS(false, false); else ABC_IKS(true, false); }
+#undef ABC_IKS
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out2, int nl, size_t count,
                       const u64 *addend, size_t addend_stride, bool add_c1) {
   if (!count) return 0;
@@ -184,7 +373,7 @@ int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, c
   const size_t N = (size_t)c->n;
   // workspace per ciphertext (words): tcoef nl + dec nl(nl+1) + prodD 2nl + prodS 2 + tmod 2nl
   const size_t per_ct = ((size_t)nl + (size_t)nl * (nl + 1) + 2 * nl + 2 + 2 * nl) * N;
-  const size_t budget_words = ((size_t)1 << 30) / 8;  // <= 1 GiB of scratch per chunk
+  const size_t budget_words = ((size_t)(c->logn > 14 ? 4 : 1) << 30) / 8;  // <= 1 GiB of scratch per chunk (big rings: 4 GiB)
   size_t chunk = budget_words / per_ct;
   if (chunk < 1) chunk = 1;
   if (chunk > count) chunk = count;
@@ -211,20 +400,32 @@ int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, c
     }
     const int fused_expand = launch_ks_expand_ntt_fp(c, tc, tcs, dec, dmap, nl, cc);
     if (fused_expand > 0) return 1;
-    if (fused_expand < 0) {
-      hipLaunchKernelGGL(k_ks_expand, dim3(grid_for(cc * nl * N, 256)), dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl, cc);
-      ABC_HIP_CHECK(hipGetLastError());
-      if (launch_ntt_fwd(c, dec, dmap, nl + 1, cc * nl * (nl + 1))) return 1;
-    }
-    hipLaunchKernelGGL(k_ks_inner, dim3(grid_for(cc * (nl + 1) * N, 256)), dim3(256), 0, c->stream, c->dc, dec, key, prodD,
-                       prodS, nl, cc);
-    ABC_HIP_CHECK(hipGetLastError());
-    if (launch_ntt_inv(c, prodS, smap, 1, cc * 2)) return 1;
-    if (launch_ks_tmod(c, prodS, tmod, nl, cc * 2)) return 1;
-    if (ckks) {
-      if (launch_ntt_fwd(c, tmod, dmap, nl, cc * 2 * nl)) return 1;
+    const int iks = fused_expand < 0 ? iks_front(c, tc, tcs, key, dec, prodD, prodS, nl, cc) : -1;
+    if (iks > 0) return 1;
+    if (iks == 0) {  // inner products done, block stages of the inverse transforms too
+      if (launch_ntt_inv_strided_part(c, prodS, smap, 1, cc * 2)) return 1;
+      if (launch_ks_tmod(c, prodS, tmod, nl, cc * 2)) return 1;
+      if (ckks) {
+        if (launch_ntt_fwd(c, tmod, dmap, nl, cc * 2 * nl)) return 1;
+      } else {
+        if (launch_ntt_inv_strided_part(c, prodD, dmap, nl, cc * 2 * nl)) return 1;
+      }
     } else {
-      if (launch_ntt_inv(c, prodD, dmap, nl, cc * 2 * nl)) return 1;
+      if (fused_expand < 0) {
+        hipLaunchKernelGGL(k_ks_expand, dim3(grid_for(cc * nl * N, 256)), dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl, cc);
+        ABC_HIP_CHECK(hipGetLastError());
+        if (launch_ntt_fwd(c, dec, dmap, nl + 1, cc * nl * (nl + 1))) return 1;
+      }
+      hipLaunchKernelGGL(k_ks_inner, dim3(grid_for(cc * (nl + 1) * N, 256)), dim3(256), 0, c->stream, c->dc, dec, key, prodD,
+                         prodS, nl, cc);
+      ABC_HIP_CHECK(hipGetLastError());
+      if (launch_ntt_inv(c, prodS, smap, 1, cc * 2)) return 1;
+      if (launch_ks_tmod(c, prodS, tmod, nl, cc * 2)) return 1;
+      if (ckks) {
+        if (launch_ntt_fwd(c, tmod, dmap, nl, cc * 2 * nl)) return 1;
+      } else {
+        if (launch_ntt_inv(c, prodD, dmap, nl, cc * 2 * nl)) return 1;
+      }
     }
     if (launch_ks_finish(c, prodD, tmod, out2 + off * 2 * nl * N, addend ? addend + off * addend_stride : nullptr, addend_stride,
                          add_c1, nl, cc))

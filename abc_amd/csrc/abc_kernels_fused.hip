@@ -290,18 +290,22 @@ const double *key_twin(abc_hip_ctx *c, const u64 *key) {
   return d;
 }
 void drop_key_twins(abc_hip_ctx *c, const u64 *key) {
-  if (c->key_twins.empty()) return;
+  if (c->key_twins.empty() && c->key_shoups.empty()) return;
   (void)hipStreamSynchronize(c->stream);
-  if (!key) {
-    for (auto &kv : c->key_twins) (void)hipFree(kv.second);
-    c->key_twins.clear();
-    return;
-  }
-  auto it = c->key_twins.find(key);
-  if (it != c->key_twins.end()) {
-    (void)hipFree(it->second);
-    c->key_twins.erase(it);
-  }
+  auto drop = [&](auto &map) {
+    if (!key) {
+      for (auto &kv : map) (void)hipFree(kv.second);
+      map.clear();
+      return;
+    }
+    auto it = map.find(key);
+    if (it != map.end()) {
+      (void)hipFree(it->second);
+      map.erase(it);
+    }
+  };
+  drop(c->key_twins);
+  drop(c->key_shoups);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -226,9 +226,9 @@ static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size
   if (!src) src = d;
   const size_t split = src2 ? total_limbs / 2 : total_limbs;  // two sources: first half of the limbs from src, second from src2
   dim3 grid((unsigned)(total_limbs << S0)), block((1 << LB) / 16);
-  // every limb of the launch must allow the unguarded butterflies; the strided pre-pass (S0 > 0) already
-  // spent part of the headroom, keep the guard there
-  bool guard = (S0 != 0);
+  // every limb of the launch must allow the unguarded butterflies.  Behind a strided pre-pass (S0 > 0: guarded, values in
+  // [0, 4q)) the at most 12 block stages add 4q each: 52q, inside the 64q the unguarded form is sized for
+  bool guard = false;
   const bool fp = all_limbs_fp(c, map, nl);  // with S0 > 0 the strided pass of the same launch makes the same choice
   for (int j = 0; j < nl; j++) guard = guard || !unguarded_ok(c->h_mods[map.id[j]].bits);
   if (fp && fwd)

@@ -105,6 +105,29 @@ def test_config5_bfv_depth8_chain(oracle_mod, capi):
     assert o.noise_budget(acc) > 0
 
 
+@pytest.mark.parametrize("n,bits", [(4096, [55, 55, 56]), (8192, [58, 52, 60, 60]), (16384, [60, 40, 40, 40, 60]), (32768, [55] * 8 + [56])])
+def test_bfv_wide_chains(n, bits, oracle_mod, capi):
+    """BFV on chains with primes above 2^50 (integer transforms, SEAL's 61-bit BEHZ auxiliary base): multiply, multiply + relinearise
+    and a batch, on ordinary and on end-of-range residues (the base conversions' lazy sums at their largest)."""
+    primes = oracle_mod.create_primes(n, bits)
+    t = oracle_mod.plain_modulus_batching(n, 20)
+    o, g = _pair(oracle_mod, capi, oracle_mod.BFV, n, primes, t, seed=91)
+    a = o.encrypt(o.encode(oracle_mod.expand_vector([3, 1, 4, 1, 5, 9, 2, 6], n)), 1)
+    b = o.encrypt(o.encode(oracle_mod.expand_vector([2, 7, 1, 8, 2, 8, 1, 8], n)), 2)
+    rng = np.random.default_rng(n)
+    ex = a.copy()  # end-of-range residues: the base conversions' lazy sums at their largest
+    for i, q in enumerate(primes[:-1]):
+        ex[:, i, :] = rng.choice(np.array([0, 1, q - 1, q - 2, q // 2, q // 2 + 1], dtype=np.uint64), size=(2, n))
+    r = g.mul_relin(a, b)
+    _eq("N=%d wide-chain mul_relin" % n, r, o.mul_relin(a, b))
+    assert list(o.decode(o.decrypt(r))[:8]) == [6, 7, 4, 8, 10, 72, 2, 48]
+    _eq("N=%d wide-chain multiply (3 components)" % n, g.multiply(r, b), o.multiply(r, b))
+    _eq("N=%d wide-chain multiply, extreme residues" % n, g.multiply(ex, ex), o.multiply(ex, ex))
+    got = g.mul_relin(np.stack([a, ex, r]), np.stack([b, a, ex]))
+    _eq("N=%d wide-chain batch row 1" % n, got[1], o.mul_relin(ex, a))
+    _eq("N=%d wide-chain batch row 2" % n, got[2], o.mul_relin(r, ex))
+
+
 @pytest.mark.parametrize("generic", [False, True, "unfused_multiply"])
 @pytest.mark.parametrize("n,bits", [(32768, [49] * 4 + [50]), (32768, [49] * 8 + [50]), (65536, [49] * 8 + [50])])
 def test_big_ring_bfv_on_an_fp64_chain(n, bits, generic, oracle_mod, capi, monkeypatch):
