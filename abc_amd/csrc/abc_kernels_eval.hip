@@ -332,6 +332,82 @@ __global__ __launch_bounds__((1 << LB) / 16, 3) void k_iks_special(DevCtx c, con
   ntt_inv_block<LB>(lds, [&](int r, int) { return acc1[r]; }, [&](int, int i, u64 v) { d1[i] = v; }, t, m, S0, b);
 }
 
+// BFV: everything behind k_iks_special in one kernel -- (ct, component, 256 positions): the strided last stages of the special
+// limb's inverse transform, N^-1, + q_sp/2 -> t (2^R values in registers); then per data prime the same stages on its limb,
+// N^-1, minus (t mod q_j + the rounding fix), times q_sp^-1, plus the addend -> coefficient form.  Replaces two strided passes
+// (in place: a read and a write of 2 (nl + 1) limbs), k_ks_tmod (2 nl limbs written, read back) and k_ks_finish.
+template <int R>
+__global__ __launch_bounds__(256) void k_iks_finish(DevCtx c, const u64 *__restrict__ prodD, const u64 *__restrict__ prodS,
+                                                    const u64 *addend, size_t addend_stride, int add_c1, u64 *out /* may be the addend */,
+                                                    int nl) {
+  const int G = c.n >> R;
+  const int per = G / 256;
+  const size_t cc = blockIdx.x / per;  // ct * 2 + comp
+  const int p = (blockIdx.x % per) * 256 + threadIdx.x;
+  const size_t ct = cc >> 1;
+  const int comp = (int)(cc & 1);
+  const size_t N = (size_t)c.n;
+  auto inverse_stages = [&](u64(&x)[1 << R], const Mod &m, const NttTable &t) {
+#pragma unroll
+    for (int u = R - 1; u >= 0; u--) {
+      const int half = 1 << (R - 1 - u);
+#pragma unroll
+      for (int k = 0; k < (1 << R); k++) {
+        if (k & half) continue;
+        const u64x2 tp = tw_load(t.itw + (1 << u) + (k >> (R - u)));
+        const u64 a = x[k], b2 = x[k | half];
+        x[k] = csub(a + b2, m.two_q);
+        x[k | half] = mul_shoup_lazy(a + m.two_q - b2, tp.x, tp.y, m.q);
+      }
+    }
+  };
+  u64 t[1 << R];
+  {
+    const Mod ms = c.mods[c.K - 1];
+    const u64 *__restrict__ src = prodS + cc * N + p;
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) t[k] = src[(size_t)k * G];
+    inverse_stages(t, ms, ntt_table(c, c.K - 1));
+    const u64 half = ms.q >> 1;
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) t[k] = add_mod(scale_inv_n(t[k], ms), half, ms.q);
+  }
+  const u64 half = c.mods[c.K - 1].q >> 1;
+  const bool add = addend && (comp == 0 || add_c1);
+#pragma nounroll
+  for (int j = 0; j < nl; j++) {
+    const Mod m = c.mods[j];
+    const u64 *__restrict__ src = prodD + (cc * nl + j) * N + p;
+    u64 x[1 << R];
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) x[k] = src[(size_t)k * G];
+    inverse_stages(x, m, ntt_table(c, j));
+    const u64 fix0 = m.q - reduce64(half, m), fix = fix0 == m.q ? 0 : fix0;
+    const u64 inv = c.cst->inv_special[j], inv_s = c.cst->inv_special_s[j];
+    u64 *o = out + (cc * nl + j) * N + p;
+    const u64 *cin = add ? addend + ct * addend_stride + ((size_t)comp * nl + j) * N + p : nullptr;
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) {
+      const u64 tm = add_mod(reduce64(t[k], m), fix, m.q);
+      u64 v = mul_shoup(sub_mod(scale_inv_n(x[k], m), tm, m.q), inv, inv_s, m.q);
+      if (add) v = add_mod(v, cin[(size_t)k * G], m.q);
+      o[(size_t)k * G] = v;
+    }
+  }
+}
+static int iks_finish(abc_hip_ctx *c, const u64 *prodD, const u64 *prodS, const u64 *addend, size_t addend_stride, bool add_c1, u64 *out,
+                      int nl, size_t cc) {
+  const int S0 = c->logn - big_block_log();
+  const int G = c->n >> S0;
+  const dim3 grid((unsigned)(cc * 2 * (G / 256)));
+  if (S0 == 3)
+    hipLaunchKernelGGL(k_iks_finish<3>, grid, dim3(256), 0, c->stream, c->dc, prodD, prodS, addend, addend_stride, add_c1 ? 1 : 0, out, nl);
+  else
+    hipLaunchKernelGGL(k_iks_finish<4>, grid, dim3(256), 0, c->stream, c->dc, prodD, prodS, addend, addend_stride, add_c1 ? 1 : 0, out, nl);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
+
 // 1: error; -1: not applicable (the caller takes the generic kernels); 0: prodS holds the special limb's sums half-way back to
 // coefficients (strided stages left), prodD the data limbs' -- likewise for BFV, in NTT form for CKKS
 static int iks_front(abc_hip_ctx *c, const u64 *tc, size_t tcs, const u64 *key, u64 *dec, u64 *prodD, u64 *prodS, int nl, size_t cc) {
@@ -402,7 +478,12 @@ int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, c
     if (fused_expand > 0) return 1;
     const int iks = fused_expand < 0 ? iks_front(c, tc, tcs, key, dec, prodD, prodS, nl, cc) : -1;
     if (iks > 0) return 1;
-    if (iks == 0) {  // inner products done, block stages of the inverse transforms too
+    if (iks == 0 && !ckks) {  // inner products done, block stages of the inverse transforms too: one kernel does the rest
+      if (iks_finish(c, prodD, prodS, addend ? addend + off * addend_stride : nullptr, addend_stride, add_c1, out2 + off * 2 * nl * N, nl, cc))
+        return 1;
+      continue;
+    }
+    if (iks == 0) {
       if (launch_ntt_inv_strided_part(c, prodS, smap, 1, cc * 2)) return 1;
       if (launch_ks_tmod(c, prodS, tmod, nl, cc * 2)) return 1;
       if (ckks) {

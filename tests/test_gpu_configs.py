@@ -106,9 +106,16 @@ def test_config5_bfv_depth8_chain(oracle_mod, capi):
 
 
 @pytest.mark.parametrize("n,bits", [(4096, [55, 55, 56]), (8192, [58, 52, 60, 60]), (16384, [60, 40, 40, 40, 60]), (32768, [55] * 8 + [56])])
-def test_bfv_wide_chains(n, bits, oracle_mod, capi):
+@pytest.mark.parametrize("variant", ["default", "no_key_mirror", "unfused"])
+def test_bfv_wide_chains(n, bits, variant, oracle_mod, capi, monkeypatch):
     """BFV on chains with primes above 2^50 (integer transforms, SEAL's 61-bit BEHZ auxiliary base): multiply, multiply + relinearise
-    and a batch, on ordinary and on end-of-range residues (the base conversions' lazy sums at their largest)."""
+    and a batch, on ordinary and on end-of-range residues (the base conversions' lazy sums at their largest).  N = 2^15: the key
+    switch takes k_iks_pass0 / k_iks_special (abc_kernels_eval.hip) -- with the key's Shoup quotients, without them
+    (ABC_HIP_NO_KEY_TWIN=1: Barrett products) -- unless ABC_HIP_NO_IKS=1."""
+    if variant == "no_key_mirror":
+        monkeypatch.setenv("ABC_HIP_NO_KEY_TWIN", "1")
+    if variant == "unfused":
+        monkeypatch.setenv("ABC_HIP_NO_IKS", "1")
     primes = oracle_mod.create_primes(n, bits)
     t = oracle_mod.plain_modulus_batching(n, 20)
     o, g = _pair(oracle_mod, capi, oracle_mod.BFV, n, primes, t, seed=91)
