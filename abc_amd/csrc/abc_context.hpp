@@ -208,7 +208,7 @@ int launch_ks_expand_ntt_fp(abc_hip_ctx *c, const u64 *tcoef, size_t tstride, u6
 int launch_ntt_fwd_from2(abc_hip_ctx *c, const u64 *src, const u64 *src2, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
 int launch_ntt_fwd_from(abc_hip_ctx *c, const u64 *src, u64 *d, const LimbMap &map, int nl, size_t total_limbs);  // out of place
 int launch_ntt_inv(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
-int launch_ntt_inv_strided_part(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs);
+int launch_ntt_inv_strided_part(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool integer_only = false);
 int big_block_log(void);
 
 int launch_addsub(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t polys, int op);  // 0 add 1 sub 2 neg

@@ -483,14 +483,10 @@ int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, c
         return 1;
       continue;
     }
-    if (iks == 0) {
-      if (launch_ntt_inv_strided_part(c, prodS, smap, 1, cc * 2)) return 1;
+    if (iks == 0) {  // CKKS: the special limb's strided stages (integers, like its block stages: k_iks_special), then as ever
+      if (launch_ntt_inv_strided_part(c, prodS, smap, 1, cc * 2, true)) return 1;
       if (launch_ks_tmod(c, prodS, tmod, nl, cc * 2)) return 1;
-      if (ckks) {
-        if (launch_ntt_fwd(c, tmod, dmap, nl, cc * 2 * nl)) return 1;
-      } else {
-        if (launch_ntt_inv_strided_part(c, prodD, dmap, nl, cc * 2 * nl)) return 1;
-      }
+      if (launch_ntt_fwd(c, tmod, dmap, nl, cc * 2 * nl)) return 1;
     } else {
       if (fused_expand < 0) {
         hipLaunchKernelGGL(k_ks_expand, dim3(grid_for(cc * nl * N, 256)), dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl, cc);

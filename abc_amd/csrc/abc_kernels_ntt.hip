@@ -247,10 +247,10 @@ static int launch_block(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size
 
 template <int R>
 static int launch_strided(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool fwd, const u64 *src = nullptr,
-                          const u64 *src2 = nullptr) {
+                          const u64 *src2 = nullptr, bool integer_only = false) {
   const int G = c->n >> R;
   dim3 grid((unsigned)(total_limbs * (G / 256))), block(256);
-  const bool fp = all_limbs_fp(c, map, nl);
+  const bool fp = !integer_only && all_limbs_fp(c, map, nl);
   if (!src) src = d;
   const size_t split = src2 ? total_limbs / 2 : total_limbs;
   if (fwd && fp)
@@ -375,10 +375,11 @@ int launch_ks_expand_ntt_fp(abc_hip_ctx *c, const u64 *tcoef, size_t tstride, u6
 
 // N > 2^14: only the strided last stages of the inverse transform (+ N^-1); the block stages were done by a kernel that fused
 // them with its own load (abc_kernels_bfv.hip, k_bfv_tensor_inv_block)
-int launch_ntt_inv_strided_part(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs) {
+// integer_only: the block stages ran in integers whatever the prime (k_iks_special), so the hand-over holds lazy u64 values, not doubles
+int launch_ntt_inv_strided_part(abc_hip_ctx *c, u64 *d, const LimbMap &map, int nl, size_t total_limbs, bool integer_only) {
   if (c->logn != 15 && c->logn != 16) { set_error("strided inverse part: N = 2^15 / 2^16 only"); return 1; }
-  return (c->logn - kBigBlockLB == 3) ? launch_strided<3>(c, d, map, nl, total_limbs, false)
-                                      : launch_strided<4>(c, d, map, nl, total_limbs, false);
+  return (c->logn - kBigBlockLB == 3) ? launch_strided<3>(c, d, map, nl, total_limbs, false, nullptr, nullptr, integer_only)
+                                      : launch_strided<4>(c, d, map, nl, total_limbs, false, nullptr, nullptr, integer_only);
 }
 int big_block_log(void) { return kBigBlockLB; }
 // N > 2^14: only the block stages of the forward transform, in place, on limbs whose strided first stages a fused kernel has done

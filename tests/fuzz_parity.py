@@ -187,9 +187,17 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-logn", type=int, default=14, help="15 adds N = 2^15 (the oracle then needs seconds per draw)")
     ap.add_argument("--max-cases", type=int, default=0)
+    ap.add_argument("--case", default="", help="replay one case: the JSON object a failed campaign printed under \"case\"")
+    ap.add_argument("--also", default="", help="with --case: extra switches for the replay, NAME=1,NAME=1")
     a = ap.parse_args()
     import oracle_py as om
     from abc_amd import capi
+    if a.case:
+        case = json.loads(a.case)
+        for kv in filter(None, a.also.split(",")):
+            case["switches"][kv.split("=")[0]] = kv.split("=")[1]
+        print(json.dumps({"result": run_case(case, om, capi, {}), "case": case}), flush=True)
+        return
     rng = np.random.default_rng(a.seed)
     contexts, counts = {}, {}
     t0 = last_note = time.time()

@@ -176,6 +176,37 @@ def test_bfv_default_8192_and_16384(oracle_mod, capi):
         _eq("BFVDefault(%d) rotate" % n, g.rotate(a, 3), o.rotate(a, 3))
 
 
+@pytest.mark.parametrize("variant", ["default", "no_key_mirror", "unfused"])
+@pytest.mark.parametrize("n,bits", [(32768, [51, 57, 50, 50]), (32768, [60, 40, 40, 60]), (65536, [55, 45, 56])])
+def test_ckks_big_ring_generic_sequence_with_the_fused_integer_key_switch(n, bits, variant, oracle_mod, capi, monkeypatch):
+    """ABC_HIP_NO_FUSED=1 at N = 2^15 / 2^16 (N = 2^16 has no other CKKS sequence): generic kernels around k_iks_pass0 / k_iks_special,
+    which keep the data limbs' sums in NTT form for CKKS and run in integers whatever the prime -- [51, 57, 50, 50] has an fp64-capable
+    SPECIAL prime under integer data primes (the strided stages behind the kernel must then be the integer ones too: found by the
+    randomised campaign) and takes the unguarded butterflies, [60, 40, 40, 60] the guarded ones.  Every level."""
+    monkeypatch.setenv("ABC_HIP_NO_FUSED", "1")
+    if variant == "no_key_mirror":
+        monkeypatch.setenv("ABC_HIP_NO_KEY_TWIN", "1")
+    if variant == "unfused":
+        monkeypatch.setenv("ABC_HIP_NO_IKS", "1")
+    primes = oracle_mod.create_primes(n, bits)
+    o, g = _pair(oracle_mod, capi, oracle_mod.CKKS, n, primes, seed=0xABC00F16)
+    rng = np.random.default_rng(n + len(bits))
+    L = len(bits) - 1
+    x = np.stack([rng.integers(0, q, size=(2, n), dtype=np.uint64) for q in primes[:L]], axis=1)
+    y = np.stack([rng.integers(0, q, size=(2, n), dtype=np.uint64) for q in primes[:L]], axis=1)
+    for j in range(L):
+        y[0, j, : n // 4] = primes[j] - 1
+        y[1, j, ::3] = 0
+    for level in range(L, 0, -1):
+        _eq("N=%d generic mul_relin level %d" % (n, level), g.mul_relin(x, y), o.mul_relin(x, y))
+        _eq("N=%d generic rotate -7 level %d" % (n, level), g.rotate(y, -7), o.rotate(y, -7))
+        if level == L:
+            got = g.rotate(np.stack([x, y, x]), 3)
+            _eq("N=%d generic batched rotate [1]" % n, got[1], o.rotate(y, 3))
+        if level > 1:
+            x, y = x[:, : level - 1].copy(), y[:, : level - 1].copy()
+
+
 @pytest.mark.parametrize("bits", [[50, 40, 40, 40, 50], [60, 40, 40, 40, 60], [57, 45, 45, 57], [50, 58, 40, 55],
                                   [50, 40, 40, 40, 40, 40, 50], [60, 45, 45, 45, 45, 45, 45, 60],
                                   [50] + [40] * 8 + [50],   # nine data limbs: the deep-chain main kernel (levels 9 and 8)
