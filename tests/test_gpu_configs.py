@@ -176,6 +176,22 @@ def test_bfv_default_8192_and_16384(oracle_mod, capi):
         _eq("BFVDefault(%d) rotate" % n, g.rotate(a, 3), o.rotate(a, 3))
 
 
+def test_bfv_default_32768(oracle_mod, capi):
+    """SEAL's BFVDefault(32768): fifteen 55-bit data primes + a special one (the largest ring of SEAL's parameter tables): integer
+    kernels, 16 auxiliary primes, a key switch of 15 x 16 digit transforms through k_iks_pass0 / k_iks_special / k_iks_finish."""
+    n = 32768
+    o, g = _pair(oracle_mod, capi, oracle_mod.BFV, n, oracle_mod.default_bfv_primes(n), oracle_mod.plain_modulus_batching(n, 20), seed=6)
+    assert g.L == 15
+    a = o.encrypt(o.encode(oracle_mod.expand_vector([3, 3, 1, 4, 5, 9], n)), 1)
+    b = o.encrypt(o.encode(oracle_mod.expand_vector([0, 1, 2, 1, 10, 21], n)), 2)
+    r = g.mul_relin(a, b)
+    _eq("BFVDefault(32768) mul_relin", r, o.mul_relin(a, b))
+    assert list(o.decode(o.decrypt(r))[:6]) == [0, 3, 2, 4, 50, 189]
+    _eq("BFVDefault(32768) rotate", g.rotate(r, -3), o.rotate(r, -3))
+    got = g.mul_relin(np.stack([a, r]), np.stack([r, b]))
+    _eq("BFVDefault(32768) batch row 1", got[1], o.mul_relin(r, b))
+
+
 @pytest.mark.parametrize("variant", ["default", "no_key_mirror", "unfused"])
 @pytest.mark.parametrize("n,bits", [(32768, [51, 57, 50, 50]), (32768, [60, 40, 40, 60]), (65536, [55, 45, 56])])
 def test_ckks_big_ring_generic_sequence_with_the_fused_integer_key_switch(n, bits, variant, oracle_mod, capi, monkeypatch):
