@@ -453,6 +453,7 @@ int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, c
   size_t chunk = budget_words / per_ct;
   if (chunk < 1) chunk = 1;
   if (chunk > count) chunk = count;
+  else if (count % chunk && count / chunk < 8) chunk = (count + count / chunk) / (count / chunk + 1);  // even chunks, no runt
   if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
   u64 *tcoef = (u64 *)c->ws;
   u64 *dec = tcoef + chunk * nl * N;
