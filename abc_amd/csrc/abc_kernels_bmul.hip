@@ -317,15 +317,16 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
 }
 
 // ---- host side ----
-static bool bmul_shape(const abc_hip_ctx *c) {
-  return c->scheme == 1 && c->use_fp && c->behz_fp && !c->sw.no_bmul && !c->sw.no_split && !c->sw.no_fused && c->L == 8 && c->nB == 8 &&
-         c->K == c->L + 1;
+static bool bmul_shape(const abc_hip_ctx *c, int limbs = 8) {
+  return c->scheme == 1 && c->use_fp && c->behz_fp && !c->sw.no_bmul && !c->sw.no_split && !c->sw.no_fused && c->L == limbs &&
+         c->nB == limbs && c->K == c->L + 1;
 }
 // multiply + relinearise in one sequence (N = 2^14)
 bool bmul_applies(const abc_hip_ctx *c) { return c->logn == 14 && bmul_shape(c) && bsplit_applies(c, c->L); }
 // the multiply alone (size-3 product): also N = 2^15 / 2^16 over the 4096-point blocks of the big-ring transforms
 bool bmul_multiply_applies(const abc_hip_ctx *c) {
   if (c->logn == 14) return bmul_applies(c);
+  if (c->logn == 13) return bmul_shape(c, 4);  // BFVDefault(8192): four data limbs, radix-8 cross passes over eight 1024-point blocks
   return (c->logn == 15 || c->logn == 16) && bmul_shape(c) && !c->sw.no_gsplit && big_block_log() == 12;
 }
 
@@ -360,6 +361,14 @@ static int bmul_big(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_
     double *X = (double *)c->ws, *Y = X + cc * 4 * nlm * N;
     const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
     u64 *po = out3 + off * 3 * L * N;
+    if (c->logn == 13) {
+      hipLaunchKernelGGL((k_bmul_front<13, 3, 4, 4>), dim3((unsigned)(cc * 4 * 16)), dim3(512), lds, st, c->dc, pa, pb, X);
+      hipLaunchKernelGGL((k_bmul_mid<13, 10>), dim3((unsigned)(cc * nlm * 8)), dim3(256), (size_t)(4 * lds_words(10)) * 8, st, c->dc,
+                         (const double *)X, Y, nlm, L);
+      hipLaunchKernelGGL((k_bmul_back<13, 3, 4, 4>), dim3((unsigned)(cc * 3 * 16)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, 1);
+      ABC_HIP_CHECK(hipGetLastError());
+      continue;
+    }
     if (c->logn == 16)
       hipLaunchKernelGGL((k_bmul_front<16, 4, 8, 8>), dim3((unsigned)(cc * 4 * 128)), dim3(512), lds, st, c->dc, pa, pb, X);
     else

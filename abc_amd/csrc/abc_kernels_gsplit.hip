@@ -1142,8 +1142,9 @@ __global__ __launch_bounds__(256) void k_bsplit_finish_lds(DevCtx c, const doubl
   }
 }
 
+// N = 2^13 (BFVDefault(8192): eight 1024-point blocks, radix-8 cross passes in registers) takes the same sequence
 bool bsplit_big_applies(const abc_hip_ctx *c, int nl) {
-  if ((c->logn != 15 && c->logn != 16) || c->scheme != 1 || !c->use_fp || c->sw.no_bsplit || c->sw.no_gsplit || nl < 1 || nl > 8) return false;
+  if ((c->logn != 13 && c->logn != 15 && c->logn != 16) || c->scheme != 1 || !c->use_fp || c->sw.no_bsplit || c->sw.no_gsplit || nl < 1 || nl > 8) return false;
   for (int j = 0; j < c->K; j++)
     if (!fp_ok(c->h_mods[j].bits)) return false;
   return true;
@@ -1155,7 +1156,11 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
   constexpr int NB = 1 << (LOGN - 10);
   const size_t PS = (size_t)c->dc.ps;
   double *part = scratch, *half = part + cc * (size_t)nl * (nl + 1) * PS, *tco = half + cc * 2 * (size_t)(nl + 1) * PS;
-  if (c->sw.no_finish_lds)
+  constexpr bool REG = LOGN < 15;  // cross passes of at most 16 values stay in registers
+  if constexpr (REG)
+    hipLaunchKernelGGL((k_bsplit_pass0<LOGN>), dim3((unsigned)(cc * nl * (nl + 1) * 4)), dim3(256), 0, st, c->dc, target, target_stride, part,
+                       nl);
+  else if (c->sw.no_finish_lds)
     hipLaunchKernelGGL((k_bsplit_pass0<LOGN>), dim3((unsigned)(cc * nl * (nl + 1) * 4)), dim3(256), 0, st, c->dc, target, target_stride, part,
                        nl);
   else
@@ -1178,7 +1183,10 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
   }
 #undef ABC_BSPB
   hipLaunchKernelGGL((k_bsplit_tcoef<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, half, tco, nl);
-  if (c->sw.no_finish_lds)
+  if constexpr (REG)
+    hipLaunchKernelGGL((k_bsplit_finish_big<LOGN>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
+                       addend_stride, add_c1, out, nl);
+  else if (c->sw.no_finish_lds)
     hipLaunchKernelGGL((k_bsplit_finish_big<LOGN>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
                        addend_stride, add_c1, out, nl);
   else
@@ -1202,6 +1210,10 @@ int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u6
     const u64 *tg = target + off * target_stride;
     const u64 *ad = addend ? addend + off * addend_stride : nullptr;
     u64 *o = out + off * 2 * (size_t)nl * N;
+    if (c->logn == 13) {
+      if (bsplit_big_chunk<13>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o)) return 1;
+      continue;
+    }
     const int rc = (c->logn == 15)
                        ? bsplit_big_chunk<15>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o)
                        : bsplit_big_chunk<16>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o);

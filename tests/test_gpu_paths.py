@@ -159,6 +159,40 @@ def test_bfv14_keyswitch_paths_bit_exact(variant, oracle_mod, capi, monkeypatch)
     g.close()
 
 
+@pytest.mark.parametrize("variant", ["default", "bfv_unsplit_multiply", "bfv_v1_keyswitch", "bfv_seal_aux_base", "integer_transforms"])
+def test_bfv13_split_paths_bit_exact(variant, oracle_mod, capi, monkeypatch):
+    """BFVDefault(8192) (four 43/44-bit data primes + special): the split multiply (k_bmul_front / _mid / _back<13, 3, 4, 4>, radix-8
+    cross passes over eight 1024-point blocks) and the split key switch (k_bsplit_pass0 / k_gsplit_special / k_bsplit_tcoef /
+    k_bsplit_finish_big<13>) against the oracle, and the LDS-resident kernels they replace (ABC_HIP_NO_BMUL / ABC_HIP_NO_BSPLIT)."""
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    o = oracle_mod.Oracle.bfv_default(8192)
+    o.keygen(0xABC00013)
+    g = capi.Context.bfv_default(8192)
+    g.load_keys(sk=o.secret_key(), pk=o.public_key(), relin=o.relin_key(),
+                galois={e: o.galois_key(e) for e in o.galois_elts()})
+    rng = np.random.default_rng(13)
+    nl = len(o.primes) - 1
+    ex = _extreme_ct(o.primes, nl, o.n, rng)
+    ct = o.encrypt(o.encode(oracle_mod.expand_vector([3, 1, 4, 1, 5], o.n)), 9)
+    _same(variant + " bfv13 multiply (size 3)", g.multiply(ct, ex), o.multiply(ct, ex))
+    _same(variant + " bfv13 mul_relin", g.mul_relin(ct, ct), o.mul_relin(ct, ct))
+    _same(variant + " bfv13 mul_relin extreme", g.mul_relin(ex, ex), o.mul_relin(ex, ex))
+    _same(variant + " bfv13 rotate extreme", g.rotate(ex, 1), o.rotate(ex, 1))
+    t3 = o.multiply(ct, ct)
+    _same(variant + " bfv13 relinearize", g.relinearize(t3), o.relinearize(t3))
+    big = np.stack([ct if i % 3 else ex for i in range(37)])  # ragged against every group size in the kernels
+    rot = g.rotate(big, -5)
+    _same(variant + " bfv13 batched rotate [0]", rot[0], o.rotate(ex, -5))
+    _same(variant + " bfv13 batched rotate [36]", rot[36], o.rotate(ex, -5))
+    _same(variant + " bfv13 batched rotate [1]", rot[1], o.rotate(ct, -5))
+    mr = g.mul_relin(big, big[::-1].copy())
+    _same(variant + " bfv13 batched mul_relin [1]", mr[1], o.mul_relin(ct, ct))
+    _same(variant + " bfv13 batched mul_relin [0]", mr[0], o.mul_relin(ex, ex))
+    _same(variant + " bfv13 batched mul_relin [35]", mr[35], o.mul_relin(ct, ct))
+    g.close()
+
+
 def test_fp64_and_integer_paths_agree_on_random_residues(oracle14, capi, monkeypatch):
     """2 000 random ciphertext pairs (uniform residues, plus rows forced to the ends of [0, q)): the fp64 kernels and the
     integer kernels must agree word for word -- a rounding slip in the fp64 quotient estimate that left the exact range
