@@ -263,6 +263,8 @@ int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u6
                size_t addend_stride, bool add_c1);
 int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
                   size_t addend_stride, int add_c1, u64 *out);
+int bsplit_back13(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
+                  size_t addend_stride, int add_c1, u64 *out);
 // the fp64 twin of a key-switching key (nullptr: not available -- capture in progress and not built yet, or allocation failed)
 const double *key_twin(abc_hip_ctx *c, const u64 *key);
 void drop_key_twins(abc_hip_ctx *c, const u64 *key /* nullptr: all */);

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
     }
     if (to_out) return;
   }
-  if constexpr (LOGN == 14) {
+  if constexpr (LOGN <= 14) {
     __syncthreads();
     // key switch, first step: digit J of c2 at this position group, forward cross pass modulo every key prime I (two halves of
     // the key primes on two sets of wavefronts) -> part[ct][I][J], the layout k_gsplit_special<14, L, true> reads
@@ -322,7 +322,10 @@ static bool bmul_shape(const abc_hip_ctx *c, int limbs = 8) {
          c->nB == limbs && c->K == c->L + 1;
 }
 // multiply + relinearise in one sequence (N = 2^14)
-bool bmul_applies(const abc_hip_ctx *c) { return c->logn == 14 && bmul_shape(c) && bsplit_applies(c, c->L); }
+bool bmul_applies(const abc_hip_ctx *c) {
+  if (c->logn == 13) return bmul_shape(c, 4) && bsplit_big_applies(c, c->L);  // BFVDefault(8192)
+  return c->logn == 14 && bmul_shape(c) && bsplit_applies(c, c->L);
+}
 // the multiply alone (size-3 product): also N = 2^15 / 2^16 over the 4096-point blocks of the big-ring transforms
 bool bmul_multiply_applies(const abc_hip_ctx *c) {
   if (c->logn == 14) return bmul_applies(c);
@@ -397,10 +400,11 @@ static int bmul_big(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_
 // relin = true: out [count][2][L][N] = relinearised product; false: out [count][3][L][N] = the size-3 product
 int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t count, bool relin) {
   if (!count) return 0;
-  if (c->logn != 14) {
-    if (relin) { set_error("bmul_split: multiply + relinearise in one sequence is an N = 2^14 path"); return 1; }
+  if (c->logn > 14 || (c->logn == 13 && !relin)) {
+    if (relin) { set_error("bmul_split: multiply + relinearise in one sequence is an N = 2^13 / 2^14 path"); return 1; }
     return bmul_big(c, a, b, out, count);
   }
+  const bool n13 = c->logn == 13;
   const size_t N = (size_t)c->n, PS = (size_t)c->dc.ps;
   const int L = c->L, nlm = c->L + c->nBsk;
   const size_t per_ct = bmul_scratch_words(c);
@@ -423,6 +427,14 @@ int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t coun
     double *X = (double *)c->ws + (size_t)ln * chunk * per_ct, *Y = X + cc * Xw;
     const u64 *pa = a + off * 2 * L * N, *pb = b + off * 2 * L * N;
     u64 *po = out + off * (relin ? 2 : 3) * L * N;
+    if (n13) {  // four data limbs, eight blocks (reached with relin only: the plain multiply of this ring is bmul_big's)
+      hipLaunchKernelGGL((k_bmul_front<13, 3, 4, 4>), dim3((unsigned)(cc * 4 * 16)), dim3(512), lds, st, c->dc, pa, pb, X);
+      hipLaunchKernelGGL((k_bmul_mid<13, 10>), dim3((unsigned)(cc * nlm * 8)), dim3(256), (size_t)(4 * lds_words(10)) * 8, st, c->dc, (const double *)X, Y, nlm, L);
+      hipLaunchKernelGGL((k_bmul_back<13, 3, 4, 4>), dim3((unsigned)(cc * 3 * 16)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, 0);
+      ABC_HIP_CHECK(hipGetLastError());
+      if (bsplit_back13(c, st, cc, L, (const double *)X, Y, c->d_relin, po, 2 * (size_t)L * N, 1, po)) return 1;
+      continue;
+    }
     hipLaunchKernelGGL((k_bmul_front<14, 4, 8, 8>), dim3((unsigned)(cc * 4 * 32)), dim3(512), lds, st, c->dc, pa, pb, X);
     hipLaunchKernelGGL((k_bmul_mid<14, 10>), dim3((unsigned)(cc * nlm * 16)), dim3(256), (size_t)(4 * lds_words(10)) * 8, st, c->dc, (const double *)X, Y, nlm, L);
     hipLaunchKernelGGL((k_bmul_back<14, 4, 8, 8>), dim3((unsigned)(cc * 3 * 32)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, relin ? 0 : 1);

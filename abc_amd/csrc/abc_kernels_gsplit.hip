@@ -905,6 +905,30 @@ int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
   return 0;
 }
 
+// the same three launches behind a `part` of eight blocks (N = 2^13: abc_kernels_bmul.hip writes it behind the floor, as at 2^14)
+int bsplit_back13(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
+                  size_t addend_stride, int add_c1, u64 *out) {
+  const dim3 g((unsigned)(cc * (nl + 1) * 8));
+  const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
+#define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<13, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
+  switch (nl) {
+    case 1: ABC_BSP(1); break;
+    case 2: ABC_BSP(2); break;
+    case 3: ABC_BSP(3); break;
+    case 4: ABC_BSP(4); break;
+    case 5: ABC_BSP(5); break;
+    case 6: ABC_BSP(6); break;
+    case 7: ABC_BSP(7); break;
+    default: ABC_BSP(8); break;
+  }
+#undef ABC_BSP
+  double *tco = half + cc * 2 * (size_t)(nl + 1) * (size_t)c->dc.ps;
+  hipLaunchKernelGGL((k_bsplit_tcoef<13>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, half, tco, nl);
+  hipLaunchKernelGGL((k_bsplit_finish_big<13>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
+                     addend_stride, add_c1, out, nl);
+  ABC_HIP_CHECK(hipGetLastError());
+  return 0;
+}
 
 // ---- BFV, N = 2^15 / 2^16 (coefficient-form ciphertexts, every key prime below 2^50): the same three steps with NB = 32 / 64 ----
 // B1 k_bsplit_pass0   (ct, J, key prime I, quarter): digit J of the operand, read as it lies (no reduction modulo q_I is needed in
