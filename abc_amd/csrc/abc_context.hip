@@ -41,6 +41,7 @@ void read_switches(abc_hip_ctx *c) {
   s.no_bmul_mid = env_on("ABC_HIP_NO_BMUL_MID");
   s.no_finish_lds = env_on("ABC_HIP_NO_FINISH_LDS");
   s.no_iks = env_on("ABC_HIP_NO_IKS");
+  s.no_bmul_r6 = env_on("ABC_HIP_NO_BMUL_R6");
   s.no_lean_front = env_on("ABC_HIP_NO_LEAN_FRONT");
   s.no_tensor_intt = env_on("ABC_HIP_NO_TENSOR_INTT");
   s.no_galois_fusion = env_on("ABC_HIP_NO_GALOIS_FUSION");

@@ -155,7 +155,7 @@ struct abc_hip_ctx {
   // Path switches (A/B timing and the parity tests of every fallback): the ABC_HIP_* environment variables are read
   // ONCE, when the context is created (abc_hip_ctx_reload_env re-reads them), never on the per-operation path.
   struct Switches {
-    bool no_fused = false, no_split = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, no_bsplit = false, no_mixed = false, no_pack = false, no_key_twin = false, no_special8x2 = false, no_bmul = false, no_bmul_mid = false, no_finish_lds = false, no_iks = false, no_tensor_intt = false;
+    bool no_fused = false, no_split = false, no_split4 = false, no_isplit = false, no_gsplit = false, no_lean_front = false, no_bsplit = false, no_mixed = false, no_pack = false, no_key_twin = false, no_special8x2 = false, no_bmul = false, no_bmul_mid = false, no_finish_lds = false, no_iks = false, no_bmul_r6 = false, no_tensor_intt = false;
     bool no_galois_fusion = false;
     size_t chunk = 0, few_limbs = 48, lean_limit = 96, bfv_scratch_mb = 0, pass0_target_limit = 128;
     int lanes = 2;

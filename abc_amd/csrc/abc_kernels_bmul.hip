@@ -84,27 +84,39 @@ __device__ __forceinline__ void m_inv_cross(double (&x)[1 << R], const FpTable &
   }
 }
 
+// tile [limb][block][position] of M1 / M3.  R > 4 (two-level cross passes): one position group of padding after every eight
+// block rows -- the second level's lanes are (group of eight blocks, position), and unpadded their rows lie 8 P doubles apart: on
+// the same LDS banks.
+template <int R, int NBLK, int P>
+__device__ __forceinline__ int m_tix(int l, int blk, int p) {
+  const int row = l * NBLK + blk;
+  return (R > 4 ? row + (row >> 3) : row) * P + p;
+}
+
 }  // namespace
 
 // ---- M1 ----
 // LOGN, R: ring and radix of the cross pass: the 2^R values one cross pass takes are N >> R apart (N = 2^14: R = 4 over 1024-point
 // blocks; N = 2^15 / 2^16: R = 3 / 4 over the 4096-point blocks of the big-ring transforms, abc_kernels_ntt.hip).  A workgroup
 // takes 512 coefficients: 2^R blocks x P = 512 >> R positions.
-template <int LOGN, int R, int LT, int NBT>
-__global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b, double *__restrict__ hA) {
+template <int LOGN, int R, int LT, int NBT, int NT = 512>
+__global__ __launch_bounds__(NT, 4) void k_bmul_front(DevCtx c, const u64 *__restrict__ a, const u64 *__restrict__ b, double *__restrict__ hA) {
   constexpr int L = LT, nBsk = NBT + 1, NLM = L + nBsk;
   constexpr int NBLK = 1 << R, P = 512 >> R, LOGP = 9 - R, SH = LOGN - R, NPG = (1 << SH) / P;
   constexpr size_t N = (size_t)1 << LOGN;
   extern __shared__ double dyn[];  // [NLM][NBLK][P]
   const ABC_CONST_AS DevConst &k = *(const ABC_CONST_AS DevConst *)c.cst;
   const ABC_CONST_AS DevConstFp &f = *(const ABC_CONST_AS DevConstFp *)c.cstf;
-  const int pg = (int)(blockIdx.x % (unsigned)NPG);
-  const int poly = (int)((blockIdx.x / (unsigned)NPG) & 3u);  // a0, a1, b0, b1
-  const size_t ct = blockIdx.x / (unsigned)(NPG * 4);
+  // R > 4: a workgroup's rows in HBM are P = 8 or 16 coefficients (half a 128-byte line or one): neighbouring position groups go to
+  // the same XCD, back to back, so the other half of a line is found in that XCD's L2 (consecutive ids alternate over the eight XCDs)
+  const unsigned wid = R > 4 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int pg = (int)(wid % (unsigned)NPG);
+  const int poly = (int)((wid / (unsigned)NPG) & 3u);  // a0, a1, b0, b1
+  const size_t ct = wid / (unsigned)(NPG * 4);
   const int tid = threadIdx.x;
   const size_t pw = (size_t)L * N;
   const u64 *__restrict__ src = (poly < 2 ? a : b) + ct * 2 * pw + (size_t)(poly & 1) * pw;
-  {  // one coefficient per thread: (block kb, position p)
+  if (NT == 512 || tid < 512) {  // one coefficient per thread: (block kb, position p); NT = 576: a ninth wavefront for the cross passes
     const int kb = tid >> LOGP, p = tid & (P - 1);
     const size_t x = ((size_t)kb << SH) + (size_t)(pg * P) + p;
     u64 raw[L];
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__re
     for (int i = 0; i < L; i++) {
       const Mod m = mod_at(c, i);
       const double v0 = fp_from_u64(raw[i]);
-      dyn[(i * NBLK + kb) * P + p] = v0;
+      dyn[m_tix<R, NBLK, P>(i, kb, p)] = v0;
       const double v = m_canon_d(fp_mul_lazy(v0, f.ext_q[i][0], f.ext_q[i][1], m.qd), m.qd, m.qinv);
       tmp[i] = v;
       mt += (u32)(u64)__double_as_longlong(v + 4503599627370496.0) * (u32)k.q_to_mtilde[i];  // mod 2^32 on the canonical residue
@@ -133,20 +145,67 @@ __global__ __launch_bounds__(512, 4) void k_bmul_front(DevCtx c, const u64 *__re
       for (int i = 0; i < L; i++) conv += fp_mul_lazy(tmp[i], row[2 * i], row[2 * i + 1], m.qd);
       const double v = m_canon_d(fp_mul_lazy(conv, f.inv_mtilde_mod_bsk[j][0], f.inv_mtilde_mod_bsk[j][1], m.qd), m.qd, m.qinv);
       dep = (u64)__double_as_longlong(v);
-      dyn[((L + j) * NBLK + kb) * P + p] = v;
+      dyn[m_tix<R, NBLK, P>((L + j), kb, p)] = v;
     }
   }
   __syncthreads();
-  for (int job = tid; job < NLM * P; job += 512) {  // one (limb, position) column per thread; the last limb is a second round
-    const int l = job >> LOGP, p = job & (P - 1);
-    const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
-    double x[NBLK];
+  if constexpr (R > 4) {
+    // radix-2^R cross pass in two levels through the tile (2^R values per column do not fit a thread: 32 values ran the inverse
+    // pass at half speed, abc DESIGN section 7): stages 0..RB-1 on the 2^RB blocks 8 apart, in place; stages RB..R-1 on 8
+    // consecutive blocks, out to hA.  Jobs are (limb, group, position) with the position fastest: 8 P lanes = one limb per wavefront.
+    constexpr int RB = R - 3, NH = 1 << RB;
+    for (int job = tid; job < NLM * 8 * P; job += NT) {
+      const int p = job & (P - 1), g = (job >> LOGP) & 7;
+      const int l = __builtin_amdgcn_readfirstlane(job >> (LOGP + 3));  // 8 P = 64 or 128 jobs per limb: wavefront-uniform
+      const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
+      double y[NH];
 #pragma unroll
-    for (int kb = 0; kb < NBLK; kb++) x[kb] = dyn[(l * NBLK + kb) * P + p];
-    m_fwd_cross<R>(x, lm.t, lm.kk);
-    double *__restrict__ dst = hA + ((ct * 4 + poly) * NLM + l) * N + (size_t)(pg * P) + p;
+      for (int h = 0; h < NH; h++) y[h] = dyn[m_tix<R, NBLK, P>(l, (h << 3) + g, p)];
 #pragma unroll
-    for (int kb = 0; kb < NBLK; kb++) dst[(size_t)kb << SH] = x[kb];
+      for (int u = 0; u < RB; u++) {
+        const int hf = 1 << (RB - 1 - u);
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+          if (h & hf) continue;
+          FpArith::fwd(y[h], y[h | hf], tw_load(lm.t.tw + (1 << u) + (h >> (RB - u))), lm.kk);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NH; h++) dyn[m_tix<R, NBLK, P>(l, (h << 3) + g, p)] = y[h];
+    }
+    __syncthreads();
+    for (int job = tid; job < NLM * NH * P; job += NT) {
+      const int p = job & (P - 1), jg = (job >> LOGP) & (NH - 1);
+      const int l = __builtin_amdgcn_readfirstlane(job >> (LOGP + RB));
+      const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
+      double v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = dyn[m_tix<R, NBLK, P>(l, (jg << 3) + j, p)];
+#pragma unroll
+      for (int u = RB; u < R; u++) {
+        const int hf = 1 << (R - 1 - u);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (j & hf) continue;
+          FpArith::fwd(v[j], v[j | hf], tw_load(lm.t.tw + (1 << u) + (((jg << 3) + j) >> (R - u))), lm.kk);
+        }
+      }
+      double *__restrict__ dst = hA + ((ct * 4 + poly) * NLM + l) * N + (size_t)(pg * P) + p;
+#pragma unroll
+      for (int j = 0; j < 8; j++) dst[(size_t)((jg << 3) + j) << SH] = v[j];
+    }
+  } else {
+    for (int job = tid; job < NLM * P; job += 512) {  // one (limb, position) column per thread; the last limb is a second round
+      const int l = job >> LOGP, p = job & (P - 1);
+      const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
+      double x[NBLK];
+#pragma unroll
+      for (int kb = 0; kb < NBLK; kb++) x[kb] = dyn[m_tix<R, NBLK, P>(l, kb, p)];
+      m_fwd_cross<R>(x, lm.t, lm.kk);
+      double *__restrict__ dst = hA + ((ct * 4 + poly) * NLM + l) * N + (size_t)(pg * P) + p;
+#pragma unroll
+      for (int kb = 0; kb < NBLK; kb++) dst[(size_t)kb << SH] = x[kb];
+    }
   }
 }
 
@@ -208,30 +267,77 @@ __global__ __launch_bounds__(4 * ((1 << LB) / 16)) void k_bmul_mid(DevCtx c, con
 // ---- M3 ----
 // want3 = 1: plain multiply, all three components to out [ct][3][L][N], no key-switch pass (the only form for N > 2^14, whose key
 // switch decomposes over 1024-point blocks: abc_kernels_gsplit.hip, bsplit_big)
-template <int LOGN, int R, int LT, int NBT>
-__global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__restrict__ hD, u64 *__restrict__ out, double *__restrict__ part,
+template <int LOGN, int R, int LT, int NBT, int NT = 512>
+__global__ __launch_bounds__(NT, 4) void k_bmul_back(DevCtx c, const double *__restrict__ hD, u64 *__restrict__ out, double *__restrict__ part,
                                                       int want3) {
   constexpr int L = LT, nB = NBT, nBsk = NBT + 1, NLM = L + nBsk;
   constexpr int NBLK = 1 << R, P = 512 >> R, LOGP = 9 - R, SH = LOGN - R, NPG = (1 << SH) / P;
   constexpr size_t N = (size_t)1 << LOGN;
   extern __shared__ double dyn[];  // [NLM][NBLK][P]
   const ABC_CONST_AS DevConstFp &f = *(const ABC_CONST_AS DevConstFp *)c.cstf;
-  const int pg = (int)(blockIdx.x % (unsigned)NPG);
-  const int comp = (int)((blockIdx.x / (unsigned)NPG) % 3u);
-  const size_t ct = (size_t)((blockIdx.x / (unsigned)NPG) / 3u);
+  const unsigned wid = R > 4 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // as in k_bmul_front
+  const int pg = (int)(wid % (unsigned)NPG);
+  const int comp = (int)((wid / (unsigned)NPG) % 3u);
+  const size_t ct = (size_t)((wid / (unsigned)NPG) / 3u);
   const int tid = threadIdx.x;
-  for (int job = tid; job < NLM * P; job += 512) {  // inverse cross pass + N^-1 of one (limb, position) column
-    const int l = job >> LOGP, p = job & (P - 1);
-    const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
-    const double *__restrict__ src = hD + ((ct * 3 + comp) * NLM + l) * N + (size_t)(pg * P) + p;
-    double x[NBLK];
+  if constexpr (R > 4) {  // two levels through the tile (see k_bmul_front): stages R-1..RB on 8 consecutive blocks, then RB-1..0 on blocks 8 apart
+    constexpr int RB = R - 3, NH = 1 << RB;
+    for (int job = tid; job < NLM * NH * P; job += NT) {
+      const int p = job & (P - 1), jg = (job >> LOGP) & (NH - 1);
+      const int l = __builtin_amdgcn_readfirstlane(job >> (LOGP + RB));
+      const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
+      const double *__restrict__ src = hD + ((ct * 3 + comp) * NLM + l) * N + (size_t)(pg * P) + p;
+      double v[8];
 #pragma unroll
-    for (int kb = 0; kb < NBLK; kb++) x[kb] = fp_centre(src[(size_t)kb << SH], lm.kk.q, lm.kk.qinv);
-    m_inv_cross<R>(x, lm.t, lm.kk);
+      for (int j = 0; j < 8; j++) v[j] = fp_centre(src[(size_t)((jg << 3) + j) << SH], lm.kk.q, lm.kk.qinv);
 #pragma unroll
-    for (int kb = 0; kb < NBLK; kb++) dyn[(l * NBLK + kb) * P + p] = fp_mul_lazy(x[kb], lm.inv_n_c, lm.inv_n_cq, lm.kk.q);
+      for (int u = R - 1; u >= RB; u--) {
+        const int hf = 1 << (R - 1 - u);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (j & hf) continue;
+          FpArith::inv(v[j], v[j | hf], tw_load(lm.t.itw + (1 << u) + (((jg << 3) + j) >> (R - u))), lm.kk);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) dyn[m_tix<R, NBLK, P>(l, (jg << 3) + j, p)] = fp_centre(v[j], lm.kk.q, lm.kk.qinv);
+    }
+    __syncthreads();
+    for (int job = tid; job < NLM * 8 * P; job += NT) {
+      const int p = job & (P - 1), g = (job >> LOGP) & 7;
+      const int l = __builtin_amdgcn_readfirstlane(job >> (LOGP + 3));  // 8 P = 64 or 128 jobs per limb: wavefront-uniform
+      const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
+      double x[NH];
+#pragma unroll
+      for (int h = 0; h < NH; h++) x[h] = dyn[m_tix<R, NBLK, P>(l, (h << 3) + g, p)];
+#pragma unroll
+      for (int u = RB - 1; u >= 0; u--) {
+        const int hf = 1 << (RB - 1 - u);
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+          if (h & hf) continue;
+          FpArith::inv(x[h], x[h | hf], tw_load(lm.t.itw + (1 << u) + (h >> (RB - u))), lm.kk);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NH; h++) dyn[m_tix<R, NBLK, P>(l, (h << 3) + g, p)] = fp_mul_lazy(x[h], lm.inv_n_c, lm.inv_n_cq, lm.kk.q);
+    }
+  } else {
+    for (int job = tid; job < NLM * P; job += 512) {  // inverse cross pass + N^-1 of one (limb, position) column
+      const int l = job >> LOGP, p = job & (P - 1);
+      const LaneMod lm = lane_mod(c, l < L ? l : c.id_bsk + (l - L));
+      const double *__restrict__ src = hD + ((ct * 3 + comp) * NLM + l) * N + (size_t)(pg * P) + p;
+      double x[NBLK];
+#pragma unroll
+      for (int kb = 0; kb < NBLK; kb++) x[kb] = fp_centre(src[(size_t)kb << SH], lm.kk.q, lm.kk.qinv);
+      m_inv_cross<R>(x, lm.t, lm.kk);
+#pragma unroll
+      for (int kb = 0; kb < NBLK; kb++) dyn[m_tix<R, NBLK, P>(l, kb, p)] = fp_mul_lazy(x[kb], lm.inv_n_c, lm.inv_n_cq, lm.kk.q);
+    }
   }
   __syncthreads();
+  static_assert(NT == 512 || LOGN > 14, "the ninth wavefront leaves here: only where no later phase needs a barrier");
+  if (NT > 512 && tid >= 512) return;
   {  // BEHZ steps (6)-(8) on one coefficient per thread (k_behz_floor_fp): scale by t, fast floor by q, Shenoy-Kumaresan back to q
     const int kb = tid >> LOGP, p = tid & (P - 1);
     const size_t x = ((size_t)kb << SH) + (size_t)(pg * P) + p;
@@ -240,7 +346,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
 #pragma unroll
     for (int i = 0; i < L; i++) {
       const Mod m = mod_at(c, i);
-      tq[i] = m_canon_d(fp_mul_lazy(dyn[(i * NBLK + kb) * P + p], f.flr_q[i][0], f.flr_q[i][1], m.qd), m.qd, m.qinv);
+      tq[i] = m_canon_d(fp_mul_lazy(dyn[m_tix<R, NBLK, P>(i, kb, p)], f.flr_q[i][0], f.flr_q[i][1], m.qd), m.qd, m.qinv);
     }
     u64 dep = (u64)__double_as_longlong(tq[L - 1]);
 #pragma unroll
@@ -250,7 +356,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
       double conv = 0.0;
 #pragma unroll
       for (int i = 0; i < L; i++) conv += fp_mul_lazy(tq[i], row[2 * i], row[2 * i + 1], m.qd);
-      const double xb = fp_mul_lazy(dyn[((L + j) * NBLK + kb) * P + p], f.tinvq_bsk[j][0], f.tinvq_bsk[j][1], m.qd);
+      const double xb = fp_mul_lazy(dyn[m_tix<R, NBLK, P>((L + j), kb, p)], f.tinvq_bsk[j][0], f.tinvq_bsk[j][1], m.qd);
       fl[j] = xb - fp_mul_lazy(conv, f.inv_q_mod_bsk[j][0], f.inv_q_mod_bsk[j][1], m.qd);
       dep = (u64)__double_as_longlong(fl[j]);
     }
@@ -282,7 +388,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
       } else {  // c2: canonical [0, q_i) as a double, the value the key switch's decomposition reduces modulo the other primes
         const double w = m_canon_d(v, m.qd, m.qinv);
         dep = (u64)__double_as_longlong(w);
-        dyn[(i * NBLK + kb) * P + p] = w;
+        dyn[m_tix<R, NBLK, P>(i, kb, p)] = w;
       }
     }
     if (to_out) return;
@@ -298,7 +404,7 @@ __global__ __launch_bounds__(512, 4) void k_bmul_back(DevCtx c, const double *__
       const int I0 = half ? (L + 2) / 2 : 0, I1 = half ? L + 1 : (L + 2) / 2;
       double x[NBLK];
 #pragma unroll
-      for (int kb = 0; kb < NBLK; kb++) x[kb] = dyn[(J * NBLK + kb) * P + p];
+      for (int kb = 0; kb < NBLK; kb++) x[kb] = dyn[m_tix<R, NBLK, P>(J, kb, p)];
       for (int I = I0; I < I1; I++) {
         const int ki = (I == L) ? c.K - 1 : I;
         const Mod m = mod_at(c, ki);
@@ -369,6 +475,24 @@ static int bmul_big(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, size_
       hipLaunchKernelGGL((k_bmul_mid<13, 10>), dim3((unsigned)(cc * nlm * 8)), dim3(256), (size_t)(4 * lds_words(10)) * 8, st, c->dc,
                          (const double *)X, Y, nlm, L);
       hipLaunchKernelGGL((k_bmul_back<13, 3, 4, 4>), dim3((unsigned)(cc * 3 * 16)), dim3(512), lds, st, c->dc, (const double *)Y, po, X, 1);
+      ABC_HIP_CHECK(hipGetLastError());
+      continue;
+    }
+    if (c->logn == 16 && !c->sw.no_bmul_r6 && !c->sw.no_bmul_mid) {  // 1024-point blocks: M2 as four workgroups per CU, radix-64 cross passes in two levels
+      const size_t lds = (size_t)nlm * 576 * 8;  // padded tile (m_tix)
+      hipLaunchKernelGGL((k_bmul_front<16, 6, 8, 8, 576>), dim3((unsigned)(cc * 4 * 128)), dim3(576), lds, st, c->dc, pa, pb, X);
+      hipLaunchKernelGGL((k_bmul_mid<16, 10>), dim3((unsigned)(cc * nlm * 64)), dim3(256), (size_t)(4 * lds_words(10)) * 8, st, c->dc,
+                         (const double *)X, Y, nlm, L);
+      hipLaunchKernelGGL((k_bmul_back<16, 6, 8, 8, 576>), dim3((unsigned)(cc * 3 * 128)), dim3(576), lds, st, c->dc, (const double *)Y, po, X, 1);
+      ABC_HIP_CHECK(hipGetLastError());
+      continue;
+    }
+    if (c->logn == 15 && !c->sw.no_bmul_r6 && !c->sw.no_bmul_mid) {  // the same at N = 2^15: radix-32 cross passes as 4 x 8, rows of 16 coefficients
+      const size_t lds = (size_t)nlm * 576 * 8;
+      hipLaunchKernelGGL((k_bmul_front<15, 5, 8, 8, 576>), dim3((unsigned)(cc * 4 * 64)), dim3(576), lds, st, c->dc, pa, pb, X);
+      hipLaunchKernelGGL((k_bmul_mid<15, 10>), dim3((unsigned)(cc * nlm * 32)), dim3(256), (size_t)(4 * lds_words(10)) * 8, st, c->dc,
+                         (const double *)X, Y, nlm, L);
+      hipLaunchKernelGGL((k_bmul_back<15, 5, 8, 8, 576>), dim3((unsigned)(cc * 3 * 64)), dim3(576), lds, st, c->dc, (const double *)Y, po, X, 1);
       ABC_HIP_CHECK(hipGetLastError());
       continue;
     }

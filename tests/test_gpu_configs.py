@@ -135,17 +135,20 @@ def test_bfv_wide_chains(n, bits, variant, oracle_mod, capi, monkeypatch):
     _eq("N=%d wide-chain batch row 2" % n, got[2], o.mul_relin(r, ex))
 
 
-@pytest.mark.parametrize("generic", [False, True, "unfused_multiply"])
+@pytest.mark.parametrize("generic", [False, True, "unfused_multiply", "multiply_on_4096_point_blocks"])
 @pytest.mark.parametrize("n,bits", [(32768, [49] * 4 + [50]), (32768, [49] * 8 + [50]), (65536, [49] * 8 + [50])])
 def test_big_ring_bfv_on_an_fp64_chain(n, bits, generic, oracle_mod, capi, monkeypatch):
     """BFV at N = 2^15 / 2^16 with every prime below 2^50 (config 5's alternative chain): the key switch takes the split
     kernels with a radix-32 / radix-64 cross pass (abc_kernels_gsplit.hip, k_bsplit_*); with ABC_HIP_NO_BSPLIT the generic
     sequence.  Eight data limbs (the BFVDefault shape): the multiply takes abc_kernels_bmul.hip's fused extension / floor kernels
-    around the 4096-point block tails; ABC_HIP_NO_BMUL selects the separate kernels.  All must give the oracle's residues."""
+    around the block tails (1024-point blocks behind two-level radix-32 / 64 cross passes; ABC_HIP_NO_BMUL_R6: 4096-point blocks);
+    ABC_HIP_NO_BMUL selects the separate kernels.  All must give the oracle's residues."""
     if generic is True:
         monkeypatch.setenv("ABC_HIP_NO_BSPLIT", "1")
     if generic == "unfused_multiply":
         monkeypatch.setenv("ABC_HIP_NO_BMUL", "1")
+    if generic == "multiply_on_4096_point_blocks":  # round 3's first form: radix-8 / 16 cross passes in registers around k_bmul_mid<.., 12>
+        monkeypatch.setenv("ABC_HIP_NO_BMUL_R6", "1")
     primes = oracle_mod.create_primes(n, bits)
     t = oracle_mod.plain_modulus_batching(n, 20)
     o, g = _pair(oracle_mod, capi, oracle_mod.BFV, n, primes, t, seed=77)

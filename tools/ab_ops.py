@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--bfv-default", action="store_true", help="BFV on BFVDefault(2^logn) instead of a CKKS chain (--bits ignored)")
+    ap.add_argument("--bfv", action="store_true", help="BFV on the --bits chain (t = Batching(n, 20))")
     a = ap.parse_args()
     import torch
     from abc_amd import capi
@@ -26,6 +27,9 @@ def main():
     if a.bfv_default:
         g = capi.Context.bfv_default(n)
         primes, nl = list(g.primes), g.L
+    elif a.bfv:
+        primes = capi.create_primes(n, bits)
+        g = capi.Context(capi.BFV, n, primes, capi.plain_modulus_batching(n, 20))
     else:
         primes = capi.create_primes(n, bits)
         g = capi.Context(capi.CKKS, n, primes)
