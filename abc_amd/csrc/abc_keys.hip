@@ -10,8 +10,12 @@
 // sampled uniform residues) -- SEAL's own PRNG stream is not reproducible by design -- and only the
 // small polynomials travel to the device; all ring arithmetic (NTTs, products, modulus switching)
 // runs in HIP kernels.
+#include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <sys/random.h>
+#include <thread>
+#include <vector>
 
 #include "abc_context.hpp"
 #include "abc_host_math.hpp"
@@ -323,14 +327,48 @@ static int encrypt_with(abc_hip_ctx *c, const u64 *plain, uint64_t seed, Sampler
   const size_t N = (size_t)c->n;
   const int K = c->K, L = c->L;
   const bool ckks = (c->scheme == 2);
-  // host sampling: per ciphertext i the stream seed+i yields u, e0, e1
+  // host sampling: per ciphertext i the stream seed+i yields u, e0, e1 -- independent streams, so a batch is drawn by up to 16
+  // host threads (the seeded spec gives the same bytes whatever the thread count; the secure path keys one ChaCha20 instance per
+  // worker from the operating system).  Config 5 encrypts 1 125 ciphertexts of 2^16 slots: 221 M draws, 530 ms on one thread.
   std::vector<int8_t> h_small(count * 3 * N);
-  for (size_t i = 0; i < count; i++) {
-    Rng seeded(seed + i);
-    Sampler &rng = secure ? *secure : static_cast<Sampler &>(seeded);
-    int8_t *p = h_small.data() + i * 3 * N;
-    for (size_t x = 0; x < N; x++) p[x] = rng.ternary();
-    for (size_t x = 0; x < 2 * N; x++) p[N + x] = rng.cbd();
+  {
+    auto fill = [N](auto &rng, int8_t *p) {  // concrete (final) generator type: the draws inline
+      for (size_t x = 0; x < N; x++) p[x] = rng.ternary();
+      for (size_t x = 0; x < 2 * N; x++) p[N + x] = rng.cbd();
+    };
+    const size_t hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t workers = count >= 4 ? std::min(hw, count) : 1;
+    std::atomic<int> failed{0};
+    auto work = [&](size_t w) {
+      const size_t i0 = count * w / workers, i1 = count * (w + 1) / workers;
+      if (secure) {
+        if (w == 0) {  // the caller's generator serves the first share
+          for (size_t i = i0; i < i1; i++) {
+            int8_t *p = h_small.data() + i * 3 * N;
+            for (size_t x = 0; x < N; x++) p[x] = secure->ternary();
+            for (size_t x = 0; x < 2 * N; x++) p[N + x] = secure->cbd();
+          }
+          return;
+        }
+        ChaCha own(0x100 + w);
+        if (!own.ok) { failed = 1; return; }
+        for (size_t i = i0; i < i1; i++) fill(own, h_small.data() + i * 3 * N);
+        return;
+      }
+      for (size_t i = i0; i < i1; i++) {
+        Rng seeded(seed + i);
+        fill(seeded, h_small.data() + i * 3 * N);
+      }
+    };
+    if (workers == 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> pool;
+      for (size_t w = 1; w < workers; w++) pool.emplace_back(work, w);
+      work(0);
+      for (auto &t : pool) t.join();
+    }
+    if (failed) { explicit_bzero(h_small.data(), h_small.size()); set_error("encrypt: getrandom failed"); return 1; }
   }
   // workspace: small 3N bytes | u [K][N] | cfull [2][K][N] | err [2][K][N] | prodD [2][L][N] | prodS [2][N] | tmod [2][L][N]
   const size_t per_ct_words = (size_t)(K + 2 * K + 2 * K + 2 * L + 2 + 2 * L) * N;

@@ -100,6 +100,24 @@ def test_encode_decode_encrypt_decrypt(bfv, oracle_mod):
     _report("decrypt size 3", g.decrypt(m3), o.decrypt(m3))
 
 
+def test_batched_encryption_draws_on_several_host_threads(bfv, oracle_mod):
+    """a batch of ciphertexts is sampled by up to 16 host threads (abc_keys.hip, encrypt_with): ciphertext i of a seeded call is
+    still the oracle's encryption under seed + i, whatever the thread count; the OS-keyed path decrypts and never repeats itself"""
+    o, g = bfv
+    pls = np.stack([o.encode(np.array(oracle_mod.expand_vector([k + 1, -k, 3 * k], o.n), dtype=np.int64)) for k in range(21)])
+    got = g.encrypt(pls, 5000)
+    for k in (0, 1, 7, 13, 20):
+        _report("seeded batch encrypt [%d]" % k, got[k], o.encrypt(pls[k], 5000 + k))
+    sec = g.encrypt(pls, None)  # abc_hip_encrypt_secure: one ChaCha20 instance per worker, keyed by getrandom(2)
+    assert sec.shape == got.shape
+    dec = g.decrypt(sec)
+    for k in range(21):
+        assert np.array_equal(dec[k], pls[k]), "secure batch encrypt: ciphertext %d does not decrypt to its plaintext" % k
+    flat = sec.reshape(21, -1)
+    assert len({flat[k, :64].tobytes() for k in range(21)}) == 21  # independent randomness per ciphertext
+    assert not np.array_equal(sec, g.encrypt(pls, None))
+
+
 def test_keygen_matches_oracle(oracle_mod, capi):
     o = oracle_mod.Oracle.bfv_default(4096)
     o.keygen(424242)
