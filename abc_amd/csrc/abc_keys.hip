@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void k_enc_mul_pk(DevCtx c, const u64 *u, cons
 
 // ---------------- key generation ----------------
 // pub draws the uniform `a` polynomials (published in the key), sec the errors; the seeded spec passes one generator as both
-static int make_kskey(abc_hip_ctx *c, Sampler &pub, Sampler &sec, const u64 *d_new_key, u64 *d_key, std::vector<uint64_t> &h_a,
+// (P, S: the generators' concrete -- final -- types, so the 156 M draws of a key set at N = 2^16 inline and the rejection limit of
+// `uniform` is computed once per prime instead of once per draw)
+template <class P, class S>
+static int make_kskey(abc_hip_ctx *c, P &pub, S &sec, const u64 *d_new_key, u64 *d_key, std::vector<uint64_t> &h_a,
                       std::vector<int8_t> &h_e, u64 *d_a, int8_t *d_e8, u64 *d_e, int nkeys) {
   const size_t N = (size_t)c->n;
   const int K = c->K;
@@ -237,7 +240,8 @@ static int make_kskey(abc_hip_ctx *c, Sampler &pub, Sampler &sec, const u64 *d_n
   return 0;
 }
 
-static int keygen_with(abc_hip_ctx *c, Sampler &pub, Sampler &sec);
+template <class P, class S>
+static int keygen_with(abc_hip_ctx *c, P &pub, S &sec);
 int keygen(abc_hip_ctx *c, uint64_t seed) {
   Rng rng(seed);
   return keygen_with(c, rng, rng);
@@ -247,7 +251,8 @@ int keygen_secure(abc_hip_ctx *c) {
   if (!sec.ok || !pub.ok) { set_error("keygen: getrandom failed"); return 1; }
   return keygen_with(c, pub, sec);
 }
-static int keygen_with(abc_hip_ctx *c, Sampler &pub, Sampler &sec) {
+template <class P, class S>
+static int keygen_with(abc_hip_ctx *c, P &pub, S &sec) {
   const size_t N = (size_t)c->n;
   const int K = c->K, L = c->L;
   LimbMap kmap{};
