@@ -1220,14 +1220,17 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
   return 0;
 }
 
-// whole call: chunks of at most 1 GiB of scratch on the context's stream (a chunk at these sizes fills the device by itself)
+// whole call: chunks of at most 1 GiB (N = 2^13) / 4 GiB of scratch on the context's stream (a chunk at these sizes fills the device by itself)
 int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count, const u64 *addend,
                size_t addend_stride, bool add_c1) {
   const size_t N = (size_t)c->n, PS = (size_t)c->dc.ps;
   const size_t per_ct = ((size_t)nl * (nl + 1) + 2 * (size_t)(nl + 1) + 2) * PS;  // part | half | tco (words)
-  size_t chunk = (((size_t)1 << 30) / 8) / per_ct;
+  // N = 2^15 / 2^16: 4 GiB of scratch, i.e. 85 ciphertexts per launch group at N = 2^16, L = 8 (1 GiB = 21: config 5 -3.5 % -- a key
+  // slice is fetched once per launch group and XCD, k_bsplit_special8x2)
+  size_t chunk = (((size_t)(c->logn > 14 ? 4 : 1) << 30) / 8) / per_ct;
   if (chunk < 1) chunk = 1;
   if (chunk > count) chunk = count;
+  else if (count % chunk && count / chunk < 8) chunk = (count + count / chunk) / (count / chunk + 1);  // even chunks, no runt
   if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
   for (size_t off = 0; off < count; off += chunk) {
     const size_t cc = (count - off < chunk) ? count - off : chunk;
