@@ -22,6 +22,10 @@
 // 502 limb transfers per multiply + relinearise where the LDS-resident sequence (bfv_multiply's six kernels + the key switch's
 // four) moved ~730 (profiles/r02g_bfv16384_traffic_per_kernel.json: 96 MB per pair).  Same arithmetic as those kernels -- exact
 // fp64 residues, every prime (ciphertext and auxiliary) below 2^50 -- bit-identical results (tests/test_gpu_paths.py).
+// Other rings, same three kernels: N = 2^13 with four data limbs (BFVDefault(8192): eight blocks, radix-8 cross passes, the whole
+// multiply + relinearise sequence); N = 2^15 / 2^16 with eight data limbs (the multiply alone; 32 / 64 blocks of 1024 points, the
+// radix-32 / 64 cross passes in two levels through the tile -- a thread holds at most eight values --, rows of 16 / 8 coefficients,
+// nine wavefronts; ABC_HIP_NO_BMUL_R6: 4096-point blocks behind radix-8 / 16 register passes, round 3's first form).
 #include <algorithm>
 
 #include "abc_context.hpp"
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(NT, 4) void k_bmul_front(DevCtx c, const u64 *__res
   __syncthreads();
   if constexpr (R > 4) {
     // radix-2^R cross pass in two levels through the tile (2^R values per column do not fit a thread: 32 values ran the inverse
-    // pass at half speed, abc DESIGN section 7): stages 0..RB-1 on the 2^RB blocks 8 apart, in place; stages RB..R-1 on 8
+    // pass at half speed): stages 0..RB-1 on the 2^RB blocks 8 apart, in place; stages RB..R-1 on 8
     // consecutive blocks, out to hA.  Jobs are (limb, group, position) with the position fastest: 8 P lanes = one limb per wavefront.
     constexpr int RB = R - 3, NH = 1 << RB;
     for (int job = tid; job < NLM * 8 * P; job += NT) {
