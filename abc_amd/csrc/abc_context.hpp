@@ -267,6 +267,7 @@ int bsplit_back13(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
                   size_t addend_stride, int add_c1, u64 *out);
 // the fp64 twin of a key-switching key (nullptr: not available -- capture in progress and not built yet, or allocation failed)
 const double *key_twin(abc_hip_ctx *c, const u64 *key);
+const double *key_twin_lookup(const abc_hip_ctx *c, const u64 *key);  // never builds: safe once the lanes have forked
 void drop_key_twins(abc_hip_ctx *c, const u64 *key /* nullptr: all */);
 // internal lanes (streams forked off the context's stream): chunks of one call alternate over them (abc_kernels_fused.hip)
 int fork_lanes(abc_hip_ctx *c, int lanes);

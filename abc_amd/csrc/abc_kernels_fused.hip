@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_key_to_fp(DevCtx c, const u64 *__restri
     keyf[i] = v > (q >> 1) ? -(double)(q - v) : (double)v;
   }
 }
-static const double *key_twin_lookup(const abc_hip_ctx *c, const u64 *key) {  // no building: safe after the lanes have forked
+const double *key_twin_lookup(const abc_hip_ctx *c, const u64 *key) {  // no building: safe after the lanes have forked
   if (c->sw.no_key_twin) return nullptr;
   auto it = c->key_twins.find(key);
   return it == c->key_twins.end() ? nullptr : it->second;
@@ -1433,7 +1433,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
   const size_t SN = (splitc || splitb) ? (size_t)c->dc.ps : N;
   const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
-  if (splitc) (void)key_twin(c, key);  // before the lanes fork
+  if (splitc || (splitb && nl == 8)) (void)key_twin(c, key);  // before the lanes fork (BFV: k_bsplit_special8x2 reads it)
   LaneScope scope(c, p.lanes);
   if (scope.fork()) return 1;
   int turn = 0;

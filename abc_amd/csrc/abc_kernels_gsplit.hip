@@ -338,6 +338,7 @@ __global__ __launch_bounds__(NL * 64, (ALL && NL == 8) ? 4 : 1) void k_gsplit_sp
 // Same arithmetic, same buffers as k_gsplit_special<LOGN, 8, true>.
 template <int LOGN>
 __global__ __launch_bounds__(256, 4) void k_bsplit_special8x2(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
+                                                               const double *__restrict__ keyf /* the key's fp64 twin, or null */,
                                                                double *__restrict__ tsp_half, int cc) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, nl = 8;
   __shared__ double dyn[4 * lds_words(10)];
@@ -373,12 +374,20 @@ __global__ __launch_bounds__(256, 4) void k_bsplit_special8x2(DevCtx c, const do
 #pragma unroll
       for (int Jx = 0; Jx < 4; Jx++) {
         const f64x2 v = *reinterpret_cast<const f64x2 *>(dyn + Jx * lds_words(10) + lds_pad(e));
-        const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)(4 * r + Jx) * 2 + 0) * c.K + ki) * N + base + e);
-        const u64x2 k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)(4 * r + Jx) * 2 + 1) * c.K + ki) * N + base + e);
-        s0[pp][0] += g_mulmod(v.x, fp_from_u64(k0.x), q, qinv);
-        s0[pp][1] += g_mulmod(v.y, fp_from_u64(k0.y), q, qinv);
-        s1[pp][0] += g_mulmod(v.x, fp_from_u64(k1.x), q, qinv);
-        s1[pp][1] += g_mulmod(v.y, fp_from_u64(k1.y), q, qinv);
+        const size_t w0 = (((size_t)(4 * r + Jx) * 2 + 0) * c.K + ki) * N + base + e, w1 = w0 + (size_t)c.K * N;
+        f64x2 y0, y1;
+        if (keyf) {  // workgroup-uniform: the words ARE the (centred) doubles, no conversion
+          y0 = *reinterpret_cast<const f64x2 *>(keyf + w0);
+          y1 = *reinterpret_cast<const f64x2 *>(keyf + w1);
+        } else {
+          const u64x2 k0 = *reinterpret_cast<const u64x2 *>(key + w0), k1 = *reinterpret_cast<const u64x2 *>(key + w1);
+          y0.x = fp_from_u64(k0.x); y0.y = fp_from_u64(k0.y);
+          y1.x = fp_from_u64(k1.x); y1.y = fp_from_u64(k1.y);
+        }
+        s0[pp][0] += g_mulmod(v.x, y0.x, q, qinv);
+        s0[pp][1] += g_mulmod(v.y, y0.y, q, qinv);
+        s1[pp][0] += g_mulmod(v.x, y1.x, q, qinv);
+        s1[pp][1] += g_mulmod(v.y, y1.y, q, qinv);
       }
     }
   }
@@ -882,7 +891,7 @@ int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
   const dim3 g((unsigned)(cc * (nl + 1) * 16));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
   if (nl == 8 && !c->sw.no_special8x2) {  // two rounds of four digits, four workgroups per CU: +2 % multiply, +5 % rotate
-    hipLaunchKernelGGL((k_bsplit_special8x2<14>), g, dim3(256), 0, st, c->dc, part, key, half, (int)cc);
+    hipLaunchKernelGGL((k_bsplit_special8x2<14>), g, dim3(256), 0, st, c->dc, part, key, key_twin_lookup(c, key), half, (int)cc);
   } else
 #define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<14, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
   switch (nl) {
@@ -1192,7 +1201,7 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
   const dim3 g((unsigned)(cc * (nl + 1) * NB));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
   if (nl == 8 && !c->sw.no_special8x2) {
-    hipLaunchKernelGGL((k_bsplit_special8x2<LOGN>), g, dim3(256), 0, st, c->dc, part, key, half, (int)cc);
+    hipLaunchKernelGGL((k_bsplit_special8x2<LOGN>), g, dim3(256), 0, st, c->dc, part, key, key_twin_lookup(c, key), half, (int)cc);
   } else
 #define ABC_BSPB(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
   switch (nl) {
@@ -1232,6 +1241,7 @@ int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u6
   if (chunk > count) chunk = count;
   else if (count % chunk && count / chunk < 8) chunk = (count + count / chunk) / (count / chunk + 1);  // even chunks, no runt
   if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
+  if (nl == 8) (void)key_twin(c, key);  // k_bsplit_special8x2 reads the key's fp64 twin where it exists
   for (size_t off = 0; off < count; off += chunk) {
     const size_t cc = (count - off < chunk) ? count - off : chunk;
     const u64 *tg = target + off * target_stride;
