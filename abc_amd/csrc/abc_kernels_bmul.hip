@@ -546,7 +546,7 @@ int bmul_split(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, size_t coun
   if (ensure_workspace(c, (size_t)lanes * chunk * per_ct * 8)) return 1;
   const size_t Xw = std::max((size_t)4 * nlm * N, (size_t)L * (L + 1) * PS);
   const size_t lds = (size_t)nlm * 512 * 8;
-  if (relin && L == 8) (void)key_twin(c, c->d_relin);  // before the lanes fork (k_bsplit_special8x2 reads it)
+  if (relin) (void)key_twin(c, c->d_relin);  // before the lanes fork (the inner-product kernel reads it)
   LaneScope scope(c, lanes);
   if (scope.fork()) return 1;
   int turn = 0;

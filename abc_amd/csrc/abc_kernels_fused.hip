@@ -1433,7 +1433,7 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
   const size_t SN = (splitc || splitb) ? (size_t)c->dc.ps : N;
   const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
-  if (splitc || (splitb && nl == 8)) (void)key_twin(c, key);  // before the lanes fork (BFV: k_bsplit_special8x2 reads it)
+  if (splitc || splitb) (void)key_twin(c, key);  // before the lanes fork (BFV: the inner-product kernel reads it)
   LaneScope scope(c, p.lanes);
   if (scope.fork()) return 1;
   int turn = 0;

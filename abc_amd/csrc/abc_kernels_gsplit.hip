@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void k_gsplit_cross(DevCtx c, const double *__
 //   [ct][I][comp] limbs -- k_bsplit_tcoef / k_bsplit_finish_big do the rest.
 template <int LOGN, int NL, bool ALL>
 __global__ __launch_bounds__(NL * 64, (ALL && NL == 8) ? 4 : 1) void k_gsplit_special(DevCtx c, const double *__restrict__ part, const u64 *__restrict__ key,
+                                                            const double *__restrict__ keyf /* the key's fp64 twin, or null */,
                                                             double *__restrict__ tsp_half, int cc) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB, nl = NL;
   extern __shared__ double dyn[];
@@ -280,12 +281,15 @@ __global__ __launch_bounds__(NL * 64, (ALL && NL == 8) ? 4 : 1) void k_gsplit_sp
   // them on the in-order vector-memory counter, which costs nothing: all of it is one burst at the start)
   constexpr bool PREFETCH = ALL && NL == 8;
   u64x2 pk0[PREFETCH ? NL : 1], pk1[PREFETCH ? NL : 1];
+  // key words: 16 raw bytes per (digit, component) either way -- the fp64 twin's words ARE the (centred) doubles (workgroup-uniform)
+  const u64 *__restrict__ kw = keyf ? reinterpret_cast<const u64 *>(keyf) : key;
+  auto kd = [&](u64 w) { return keyf ? __longlong_as_double((long long)w) : fp_from_u64(w); };
   if constexpr (PREFETCH) {
     const int e = 2 * (int)threadIdx.x;
 #pragma unroll
     for (int Jx = 0; Jx < NL; Jx++) {
-      pk0[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
-      pk1[Jx] = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
+      pk0[Jx] = *reinterpret_cast<const u64x2 *>(kw + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
+      pk1[Jx] = *reinterpret_cast<const u64x2 *>(kw + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
     }
   }
   {
@@ -306,13 +310,13 @@ __global__ __launch_bounds__(NL * 64, (ALL && NL == 8) ? 4 : 1) void k_gsplit_sp
         k0 = pk0[Jx];
         k1 = pk1[Jx];
       } else {
-        k0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
-        k1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
+        k0 = *reinterpret_cast<const u64x2 *>(kw + (((size_t)Jx * 2 + 0) * c.K + ki) * N + base + e);
+        k1 = *reinterpret_cast<const u64x2 *>(kw + (((size_t)Jx * 2 + 1) * c.K + ki) * N + base + e);
       }
-      s0[0] += g_mulmod(v.x, fp_from_u64(k0.x), q, qinv);
-      s0[1] += g_mulmod(v.y, fp_from_u64(k0.y), q, qinv);
-      s1[0] += g_mulmod(v.x, fp_from_u64(k1.x), q, qinv);
-      s1[1] += g_mulmod(v.y, fp_from_u64(k1.y), q, qinv);
+      s0[0] += g_mulmod(v.x, kd(k0.x), q, qinv);
+      s0[1] += g_mulmod(v.y, kd(k0.y), q, qinv);
+      s1[0] += g_mulmod(v.x, kd(k1.x), q, qinv);
+      s1[1] += g_mulmod(v.y, kd(k1.y), q, qinv);
       if (NL > 8 && (Jx & 7) == 7) {  // eight products of magnitude < q stay below 2^53; re-centre before adding more
         s0[0] = fp_centre(s0[0], q, qinv); s0[1] = fp_centre(s0[1], q, qinv);
         s1[0] = fp_centre(s1[0], q, qinv); s1[1] = fp_centre(s1[1], q, qinv);
@@ -749,7 +753,7 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
   const size_t lds_main = (size_t)((nl + 1) * lds_words(10)) * 8 + 1024 * 16;
   const dim3 gsp((unsigned)(cc * NB)), gmain((unsigned)(cc * nl * NB));
   if (nl > 7) {  // deep chains: one wavefront per limb still, but up to sixteen of them
-#define ABC_GSPD(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp, (int)cc)
+#define ABC_GSPD(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, key_twin_lookup(c, key), tsp, (int)cc)
     switch (nl) {
       case 8: ABC_GSPD(8); break;
       case 9: ABC_GSPD(9); break;
@@ -774,7 +778,7 @@ static void launch_gsplit_back(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
     return;
   }
 #define ABC_GSP(NLV)                                                                                                                    \
-  hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, tsp, (int)cc);                            \
+  hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, false>), gsp, dim3(64 * NLV), lds_sp, st, c->dc, part, key, key_twin_lookup(c, key), tsp, (int)cc);                            \
   hipLaunchKernelGGL((k_gsplit_pass<LOGN>), dim3((unsigned)(cc * 2 * (LOGN > 14 ? 32 : 4))), dim3(256), 0, st, c->dc, tsp, tpart, nl);  \
   if (mode == 0)                                                                                                                        \
     hipLaunchKernelGGL((k_gsplit_main<LOGN, 0, false, NLV>), gmain, dim3(512), lds_main, st, c->dc, part, tpart, opa, opb, opa_stride,  \
@@ -893,7 +897,7 @@ int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
   if (nl == 8 && !c->sw.no_special8x2) {  // two rounds of four digits, four workgroups per CU: +2 % multiply, +5 % rotate
     hipLaunchKernelGGL((k_bsplit_special8x2<14>), g, dim3(256), 0, st, c->dc, part, key, key_twin_lookup(c, key), half, (int)cc);
   } else
-#define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<14, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
+#define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<14, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, key_twin_lookup(c, key), half, (int)cc)
   switch (nl) {
     case 1: ABC_BSP(1); break;
     case 2: ABC_BSP(2); break;
@@ -919,7 +923,7 @@ int bsplit_back13(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
                   size_t addend_stride, int add_c1, u64 *out) {
   const dim3 g((unsigned)(cc * (nl + 1) * 8));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
-#define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<13, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
+#define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<13, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, key_twin_lookup(c, key), half, (int)cc)
   switch (nl) {
     case 1: ABC_BSP(1); break;
     case 2: ABC_BSP(2); break;
@@ -1203,7 +1207,7 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
   if (nl == 8 && !c->sw.no_special8x2) {
     hipLaunchKernelGGL((k_bsplit_special8x2<LOGN>), g, dim3(256), 0, st, c->dc, part, key, key_twin_lookup(c, key), half, (int)cc);
   } else
-#define ABC_BSPB(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, half, (int)cc)
+#define ABC_BSPB(NLV) hipLaunchKernelGGL((k_gsplit_special<LOGN, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, key_twin_lookup(c, key), half, (int)cc)
   switch (nl) {
     case 1: ABC_BSPB(1); break;
     case 2: ABC_BSPB(2); break;
@@ -1241,7 +1245,7 @@ int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u6
   if (chunk > count) chunk = count;
   else if (count % chunk && count / chunk < 8) chunk = (count + count / chunk) / (count / chunk + 1);  // even chunks, no runt
   if (ensure_workspace(c, chunk * per_ct * 8)) return 1;
-  if (nl == 8) (void)key_twin(c, key);  // k_bsplit_special8x2 reads the key's fp64 twin where it exists
+  (void)key_twin(c, key);  // the inner-product kernels read the key's fp64 twin where it exists
   for (size_t off = 0; off < count; off += chunk) {
     const size_t cc = (count - off < chunk) ? count - off : chunk;
     const u64 *tg = target + off * target_stride;
