@@ -260,11 +260,11 @@ void gsplit_main_deep_subset15(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
 bool bsplit_applies(const abc_hip_ctx *c, int nl);
 bool bsplit_big_applies(const abc_hip_ctx *c, int nl);
 int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count, const u64 *addend,
-               size_t addend_stride, bool add_c1);
+               size_t addend_stride, bool add_c1, u32 ginv = 0);
 int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
-                  size_t addend_stride, int add_c1, u64 *out);
+                  size_t addend_stride, int add_c1, u64 *out, u32 ginv = 0);
 int bsplit_back13(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
-                  size_t addend_stride, int add_c1, u64 *out);
+                  size_t addend_stride, int add_c1, u64 *out, u32 ginv = 0);
 // the fp64 twin of a key-switching key (nullptr: not available -- capture in progress and not built yet, or allocation failed)
 const double *key_twin(abc_hip_ctx *c, const u64 *key);
 const double *key_twin_lookup(const abc_hip_ctx *c, const u64 *key);  // never builds: safe once the lanes have forked

@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "abc_context.hpp"
+#include "abc_host_math.hpp"
 
 namespace abc {
 
@@ -606,6 +607,14 @@ __global__ __launch_bounds__((1 << LB) / 16) void k_fused_operand_pass0_fp(DevCt
           x[r] = w < 0.0 ? w + m.qd : w;
         },
         t, m, 0, 0);
+  } else if (gelt) {  // BFV rotation: gelt = elt^-1 mod 2N, the permutation (with its sign) folded into the load -- workgroup-uniform
+    const u64 qj = c.mods[j].q;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      bool neg;
+      const u64 v = sp[galois_coef_src((u32)((k << 10) + tid), gelt, LB, neg)];
+      x[k] = fp_from_u64(neg ? neg_mod(v, qj) : v);
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = fp_from_u64(sp[(k << 10) + tid]);
@@ -1430,6 +1439,9 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
   // register pass + abc_kernels_gsplit.hip's k_gsplit_special<14, NL, true> / k_bsplit_tcoef / k_bsplit_finish_big
   const bool splitc = LB == 14 && ckks && all_fp(c) && !c->sw.no_split && nl <= 12;
   const bool splitb = LB == 14 && !ckks && !c->sw.no_split && bsplit_applies(c, nl);
+  // BFV rotation (coefficient form): the kernels gather with elt^-1 mod 2N
+  const u32 ginv = (!ckks && gelt) ? (u32)host::invmod(gelt, 2 * (uint64_t)N) : 0u;
+  if (ginv && !splitb) { set_error("run_keyswitch: a BFV permutation is only folded into the split sequence"); return 1; }
   const size_t SN = (splitc || splitb) ? (size_t)c->dc.ps : N;
   const size_t per_ct = fused_scratch_limbs(nl) * SN;
   if (ensure_workspace(c, (size_t)p.lanes * p.chunk * per_ct * 8)) return 1;
@@ -1465,9 +1477,9 @@ static int run_keyswitch(abc_hip_ctx *c, const u64 *target, size_t target_stride
         // few ciphertexts in flight: one workgroup per (ct, J, target I) instead of per (ct, J)
         const bool per_target = cc * nl < c->sw.pass0_target_limit;
         hipLaunchKernelGGL((k_fused_operand_pass0_fp<LB, false, false>), dim3((unsigned)(cc * nl * (per_target ? nl + 1 : 1))),
-                           dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, per_target ? 1 : 0, 0u, 1);
-        // inner product + inverse tails for every key prime, then the register-only finish
-        if (bsplit_back14(c, st, cc, nl, (const double *)s.dec, (double *)s.ksacc, key, ad, addend_stride, add_c1 ? 1 : 0, o)) return 1;
+                           dim3((1 << LB) / 16), 0, st, c->dc, tg, target_stride, (double *)s.dec, nl, per_target ? 1 : 0, ginv, 1);
+        // inner product + inverse tails for every key prime, then the register-only finish (a rotation's addend g(c0): gathered there)
+        if (bsplit_back14(c, st, cc, nl, (const double *)s.dec, (double *)s.ksacc, key, ad, addend_stride, add_c1 ? 1 : 0, o, ginv)) return 1;
         continue;
       }
     }
@@ -1501,6 +1513,18 @@ int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *ou
     if (!count) return 0;
     const size_t pw15 = (size_t)nl * c->n;
     return run_isplit(c, 1, in + pw15, in, 2 * pw15, 2 * pw15, false, key, out, nl, count, elt);
+  }
+  if (c->scheme == 1 && in != out && !c->sw.no_galois_fusion && !c->sw.no_split && !c->sw.no_fused) {
+    // BFV, coefficient form: the signed permutation folded into the first step's load and the last step's addend (N = 2^13 / 2^14)
+    const size_t pwb = (size_t)nl * c->n;
+    if (c->logn == 14 && bsplit_applies(c, nl)) {
+      if (!count) return 0;
+      return run_keyswitch<14>(c, in + pwb, 2 * pwb, key, out, nl, count, in, 2 * pwb, false, elt);
+    }
+    if (c->logn == 13 && bsplit_big_applies(c, nl)) {
+      if (!count) return 0;
+      return bsplit_big(c, in + pwb, 2 * pwb, key, out, nl, count, in, 2 * pwb, false, (u32)host::invmod(elt, 2 * (uint64_t)c->n));
+    }
   }
   if (c->logn != 14 || c->scheme != 2 || in == out) return -1;
   if (!all_fp(c) && !isplit_applies(c, nl)) return -1;

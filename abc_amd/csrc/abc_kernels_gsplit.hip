@@ -881,7 +881,7 @@ template <int LOGN>
 __global__ void k_bsplit_tcoef(DevCtx c, const double *__restrict__ half, double *__restrict__ tco, int nl);
 template <int LOGN>
 __global__ void k_bsplit_finish_big(DevCtx c, const double *__restrict__ half, const double *__restrict__ tco, const u64 *__restrict__ addend,
-                                    size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl);
+                                    size_t addend_stride, int add_c1, u64 *__restrict__ out, int nl, u32 ginv);
 
 // half: [cc][nl+1][2] limbs at stride c->dc.ps; part as written by k_fused_operand_pass0_fp<14, false, false> (padded layout)
 bool bsplit_applies(const abc_hip_ctx *c, int nl) {
@@ -891,7 +891,7 @@ bool bsplit_applies(const abc_hip_ctx *c, int nl) {
   return true;
 }
 int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
-                  size_t addend_stride, int add_c1, u64 *out) {
+                  size_t addend_stride, int add_c1, u64 *out, u32 ginv) {
   const dim3 g((unsigned)(cc * (nl + 1) * 16));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
   if (nl == 8 && !c->sw.no_special8x2) {  // two rounds of four digits, four workgroups per CU: +2 % multiply, +5 % rotate
@@ -913,14 +913,14 @@ int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
   double *tco = half + cc * 2 * (size_t)(nl + 1) * (size_t)c->dc.ps;
   hipLaunchKernelGGL((k_bsplit_tcoef<14>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, half, tco, nl);
   hipLaunchKernelGGL((k_bsplit_finish_big<14>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
-                     addend_stride, add_c1, out, nl);
+                     addend_stride, add_c1, out, nl, ginv);
   ABC_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 // the same three launches behind a `part` of eight blocks (N = 2^13: abc_kernels_bmul.hip writes it behind the floor, as at 2^14)
 int bsplit_back13(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,
-                  size_t addend_stride, int add_c1, u64 *out) {
+                  size_t addend_stride, int add_c1, u64 *out, u32 ginv) {
   const dim3 g((unsigned)(cc * (nl + 1) * 8));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
 #define ABC_BSP(NLV) hipLaunchKernelGGL((k_gsplit_special<13, NLV, true>), g, dim3(64 * NLV), lds, st, c->dc, part, key, key_twin_lookup(c, key), half, (int)cc)
@@ -938,7 +938,7 @@ int bsplit_back13(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
   double *tco = half + cc * 2 * (size_t)(nl + 1) * (size_t)c->dc.ps;
   hipLaunchKernelGGL((k_bsplit_tcoef<13>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, half, tco, nl);
   hipLaunchKernelGGL((k_bsplit_finish_big<13>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
-                     addend_stride, add_c1, out, nl);
+                     addend_stride, add_c1, out, nl, ginv);
   ABC_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -953,7 +953,7 @@ int bsplit_back13(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const doubl
 // Replaces, for these rings, k_ks_expand_strided_fp + block transforms + k_ks_inner + transforms + k_ks_tmod + k_ks_finish.
 template <int LOGN>
 __global__ __launch_bounds__(256) void k_bsplit_pass0(DevCtx c, const u64 *__restrict__ src, size_t src_stride, double *__restrict__ part,
-                                                      int nl) {
+                                                      int nl, u32 ginv = 0 /* BFV rotation: elt^-1 mod 2N, the permutation folded into the load */) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
   const unsigned w = blockIdx.x >> 2;
@@ -967,8 +967,18 @@ __global__ __launch_bounds__(256) void k_bsplit_pass0(DevCtx c, const u64 *__res
   const FpK kk = FpArith::consts(m);
   const u64 *__restrict__ sp = src + ct * src_stride + (size_t)J * N;
   double x[NB];
+  if (ginv) {  // workgroup-uniform
+    const u64 qj = c.mods[J].q;
 #pragma unroll
-  for (int k = 0; k < NB; k++) x[k] = fp_from_u64(sp[(k << 10) + p]);
+    for (int k = 0; k < NB; k++) {
+      bool neg;
+      const u64 v = sp[galois_coef_src((u32)((k << 10) + p), ginv, LOGN, neg)];
+      x[k] = fp_from_u64(neg ? neg_mod(v, qj) : v);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NB; k++) x[k] = fp_from_u64(sp[(k << 10) + p]);
+  }
   fwd_cross<LOGNB>(x, t, kk);
   double *__restrict__ dst = part + ((ct * (nl + 1) + I) * nl + J) * PS;
 #pragma unroll
@@ -1003,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_bsplit_tcoef(DevCtx c, const double *__
 template <int LOGN>
 __global__ __launch_bounds__(256) void k_bsplit_finish_big(DevCtx c, const double *__restrict__ half, const double *__restrict__ tco,
                                                            const u64 *__restrict__ addend, size_t addend_stride, int add_c1,
-                                                           u64 *__restrict__ out, int nl) {
+                                                           u64 *__restrict__ out, int nl, u32 ginv /* BFV rotation: gather the addend */) {
   constexpr int LOGNB = LOGN - 10, NB = 1 << LOGNB;
   const int p = (int)((blockIdx.x & 3) << 8) + (int)threadIdx.x;
   const int I = (int)((blockIdx.x >> 2) % (unsigned)nl);
@@ -1033,7 +1043,15 @@ __global__ __launch_bounds__(256) void k_bsplit_finish_big(DevCtx c, const doubl
   for (int k = 0; k < NB; k++) {
     const double d = fp_mul_lazy(x[k], m.inv_n_c, m.inv_n_cq, m.qd) - (tsrc[(k << 10) + p] + fix);
     double r = fp_mul_lazy(d, inv, inv_q, m.qd);
-    if (add) r += fp_from_u64(cin[(k << 10) + p]);
+    if (add) {
+      if (ginv) {  // workgroup-uniform
+        bool neg;
+        const u64 v = cin[galois_coef_src((u32)((k << 10) + p), ginv, LOGN, neg)];
+        r += fp_from_u64(neg ? neg_mod(v, m.q) : v);
+      } else {
+        r += fp_from_u64(cin[(k << 10) + p]);
+      }
+    }
     o[(k << 10) + p] = fp_to_canon(r, m.qd, m.qinv);
   }
 }
@@ -1189,17 +1207,18 @@ bool bsplit_big_applies(const abc_hip_ctx *c, int nl) {
 
 template <int LOGN>
 static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, size_t cc, int nl, const u64 *target, size_t target_stride,
-                            const u64 *key, const u64 *addend, size_t addend_stride, int add_c1, u64 *out) {
+                            const u64 *key, const u64 *addend, size_t addend_stride, int add_c1, u64 *out, u32 ginv = 0) {
+  if (ginv && LOGN > 14) { set_error("bsplit: the folded BFV permutation is an N <= 2^14 path"); return 1; }
   constexpr int NB = 1 << (LOGN - 10);
   const size_t PS = (size_t)c->dc.ps;
   double *part = scratch, *half = part + cc * (size_t)nl * (nl + 1) * PS, *tco = half + cc * 2 * (size_t)(nl + 1) * PS;
   constexpr bool REG = LOGN < 15;  // cross passes of at most 16 values stay in registers
   if constexpr (REG)
     hipLaunchKernelGGL((k_bsplit_pass0<LOGN>), dim3((unsigned)(cc * nl * (nl + 1) * 4)), dim3(256), 0, st, c->dc, target, target_stride, part,
-                       nl);
+                       nl, ginv);
   else if (c->sw.no_finish_lds)
     hipLaunchKernelGGL((k_bsplit_pass0<LOGN>), dim3((unsigned)(cc * nl * (nl + 1) * 4)), dim3(256), 0, st, c->dc, target, target_stride, part,
-                       nl);
+                       nl, 0u);
   else
     hipLaunchKernelGGL((k_bsplit_pass0_lds<LOGN>), dim3((unsigned)(cc * nl * 32)), dim3(256), 0, st, c->dc, target, target_stride, part, nl);
   const dim3 g((unsigned)(cc * (nl + 1) * NB));
@@ -1222,10 +1241,10 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
   hipLaunchKernelGGL((k_bsplit_tcoef<LOGN>), dim3((unsigned)(cc * 2 * 4)), dim3(256), 0, st, c->dc, half, tco, nl);
   if constexpr (REG)
     hipLaunchKernelGGL((k_bsplit_finish_big<LOGN>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
-                       addend_stride, add_c1, out, nl);
+                       addend_stride, add_c1, out, nl, ginv);
   else if (c->sw.no_finish_lds)
     hipLaunchKernelGGL((k_bsplit_finish_big<LOGN>), dim3((unsigned)(cc * 2 * nl * 4)), dim3(256), 0, st, c->dc, half, tco, addend,
-                       addend_stride, add_c1, out, nl);
+                       addend_stride, add_c1, out, nl, 0u);
   else
     hipLaunchKernelGGL((k_bsplit_finish_lds<LOGN>), dim3((unsigned)(cc * 2 * nl * 32)), dim3(256), 0, st, c->dc, half, tco, addend,
                        addend_stride, add_c1, out, nl);
@@ -1235,7 +1254,7 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
 
 // whole call: chunks of at most 1 GiB (N = 2^13) / 4 GiB of scratch on the context's stream (a chunk at these sizes fills the device by itself)
 int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count, const u64 *addend,
-               size_t addend_stride, bool add_c1) {
+               size_t addend_stride, bool add_c1, u32 ginv) {
   const size_t N = (size_t)c->n, PS = (size_t)c->dc.ps;
   const size_t per_ct = ((size_t)nl * (nl + 1) + 2 * (size_t)(nl + 1) + 2) * PS;  // part | half | tco (words)
   // N = 2^15 / 2^16: 4 GiB of scratch, i.e. 85 ciphertexts per launch group at N = 2^16, L = 8 (1 GiB = 21: config 5 -3.5 % -- a key
@@ -1252,7 +1271,7 @@ int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u6
     const u64 *ad = addend ? addend + off * addend_stride : nullptr;
     u64 *o = out + off * 2 * (size_t)nl * N;
     if (c->logn == 13) {
-      if (bsplit_big_chunk<13>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o)) return 1;
+      if (bsplit_big_chunk<13>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o, ginv)) return 1;
       continue;
     }
     const int rc = (c->logn == 15)

@@ -146,4 +146,12 @@ __device__ __forceinline__ u32 galois_ntt_src(u32 i, u32 elt, int logn) {
   return bitrev32(idx, logn);
 }
 
+// Galois automorphism x -> x^elt on a COEFFICIENT-form limb as a gather: coefficient j of the result is +-coefficient i of the
+// operand with i * elt = j or j + N (mod 2N); with einv = elt^-1 mod 2N: i0 = j * einv mod 2N, i = i0 mod N, negated iff i0 >= N.
+__device__ __forceinline__ u32 galois_coef_src(u32 j, u32 einv, int logn, bool &neg) {
+  const u32 i0 = (j * einv) & ((2u << logn) - 1u);
+  neg = (i0 >> logn) & 1u;
+  return i0 & ((1u << logn) - 1u);
+}
+
 }  // namespace abc

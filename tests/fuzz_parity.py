@@ -35,6 +35,7 @@ SWITCH_SETS = [
     {"ABC_HIP_NO_SPECIAL8X2": "1"},
     {"ABC_HIP_NO_FINISH_LDS": "1"},
     {"ABC_HIP_NO_IKS": "1"},
+    {"ABC_HIP_NO_GALOIS_FUSION": "1"},
     {"ABC_HIP_NO_BMUL_R6": "1"},
     {"ABC_HIP_NO_LEAN_FRONT": "1"},
     {"ABC_HIP_NO_FUSED": "1"},

@@ -119,11 +119,12 @@ def test_ckks14_every_level_bit_exact(variant, oracle14, capi, monkeypatch):
 VARIANTS["bfv_v1_keyswitch"] = {"ABC_HIP_NO_BSPLIT": "1"}  # LDS-atomic tail kernel + LDS-resident mod-down (round 1)
 VARIANTS["bfv_unsplit_multiply"] = {"ABC_HIP_NO_BMUL": "1"}  # LDS-resident BEHZ multiply (six kernels) + the split key switch
 VARIANTS["bfv_special_one_round"] = {"ABC_HIP_NO_SPECIAL8X2": "1"}  # key-switch inner product: eight wavefronts, one round
+VARIANTS["bfv_separate_permutation"] = {"ABC_HIP_NO_GALOIS_FUSION": "1"}  # rotations: k_galois first, then the key switch
 VARIANTS["bfv_seal_aux_base"] = {"ABC_HIP_BEHZ_SEAL_BASE": "1"}  # 61-bit BEHZ auxiliary primes, as SEAL draws them
 VARIANTS["bfv_int_behz_kernels"] = {"ABC_HIP_BEHZ_INT_KERNELS": "1"}  # 50-bit base, integer base-conversion kernels
 
 
-@pytest.mark.parametrize("variant", ["default", "bfv_unsplit_multiply", "bfv_special_one_round", "bfv_v1_keyswitch", "bfv_seal_aux_base", "bfv_int_behz_kernels", "integer_transforms", "fp64_unsplit"])
+@pytest.mark.parametrize("variant", ["default", "bfv_unsplit_multiply", "bfv_special_one_round", "bfv_v1_keyswitch", "bfv_separate_permutation", "bfv_seal_aux_base", "bfv_int_behz_kernels", "integer_transforms", "fp64_unsplit"])
 def test_bfv14_keyswitch_paths_bit_exact(variant, oracle_mod, capi, monkeypatch):
     """BFVDefault(16384): 48/49-bit primes, i.e. the re-centring ('red') fp64 butterflies, coefficient-form operand"""
     for k, v in VARIANTS[variant].items():
@@ -159,7 +160,7 @@ def test_bfv14_keyswitch_paths_bit_exact(variant, oracle_mod, capi, monkeypatch)
     g.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "bfv_unsplit_multiply", "bfv_v1_keyswitch", "bfv_seal_aux_base", "integer_transforms"])
+@pytest.mark.parametrize("variant", ["default", "bfv_unsplit_multiply", "bfv_v1_keyswitch", "bfv_separate_permutation", "bfv_seal_aux_base", "integer_transforms"])
 def test_bfv13_split_paths_bit_exact(variant, oracle_mod, capi, monkeypatch):
     """BFVDefault(8192) (four 43/44-bit data primes + special): the split multiply (k_bmul_front / _mid / _back<13, 3, 4, 4>, radix-8
     cross passes over eight 1024-point blocks) and the split key switch (k_bsplit_pass0 / k_gsplit_special / k_bsplit_tcoef /
