@@ -1515,13 +1515,13 @@ int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *ou
     return run_isplit(c, 1, in + pw15, in, 2 * pw15, 2 * pw15, false, key, out, nl, count, elt);
   }
   if (c->scheme == 1 && in != out && !c->sw.no_galois_fusion && !c->sw.no_split && !c->sw.no_fused) {
-    // BFV, coefficient form: the signed permutation folded into the first step's load and the last step's addend (N = 2^13 / 2^14)
+    // BFV, coefficient form: the signed permutation folded into the first step's load and the last step's addend (fp64 chains)
     const size_t pwb = (size_t)nl * c->n;
     if (c->logn == 14 && bsplit_applies(c, nl)) {
       if (!count) return 0;
       return run_keyswitch<14>(c, in + pwb, 2 * pwb, key, out, nl, count, in, 2 * pwb, false, elt);
     }
-    if (c->logn == 13 && bsplit_big_applies(c, nl)) {
+    if ((c->logn == 13 || ((c->logn == 15 || c->logn == 16) && !c->sw.no_finish_lds)) && bsplit_big_applies(c, nl)) {
       if (!count) return 0;
       return bsplit_big(c, in + pwb, 2 * pwb, key, out, nl, count, in, 2 * pwb, false, (u32)host::invmod(elt, 2 * (uint64_t)c->n));
     }

@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(256) void k_bsplit_finish_big(DevCtx c, const doubl
 // read of the digit per key prime: 72 limb reads per ciphertext where 8 do).
 template <int LOGN>
 __global__ __launch_bounds__(256) void k_bsplit_pass0_lds(DevCtx c, const u64 *__restrict__ src, size_t src_stride, double *__restrict__ part,
-                                                          int nl) {
+                                                          int nl, u32 ginv /* BFV rotation: elt^-1 mod 2N, the permutation folded into the load */) {
   constexpr int R = LOGN - 10, NB = 1 << R, RA = 3, RB = R - RA, P = 32;
   __shared__ double lds[NB * P];
   const int pg = blockIdx.x & 31;
@@ -1075,7 +1075,16 @@ __global__ __launch_bounds__(256) void k_bsplit_pass0_lds(DevCtx c, const u64 *_
   const int p = tid & (P - 1), jg = tid >> 5;  // phase 1: j = jg (block index mod 2^RA); phase 2: g = jg (group of 2^RA blocks)
   const u64 *__restrict__ sp = src + ct * src_stride + (size_t)J * N + (size_t)(pg * P);
   double y0[1 << RB];
-  if (w1) {
+  if (w1 && ginv) {  // workgroup-uniform second condition
+    const u64 *__restrict__ limb = src + ct * src_stride + (size_t)J * N;
+    const u64 qj = c.mods[J].q;
+#pragma unroll
+    for (int h = 0; h < (1 << RB); h++) {
+      bool neg;
+      const u64 v = limb[galois_coef_src((u32)(((h << RA) + jg) * 1024 + pg * P + p), ginv, LOGN, neg)];
+      y0[h] = fp_from_u64(neg ? neg_mod(v, qj) : v);
+    }
+  } else if (w1) {
 #pragma unroll
     for (int h = 0; h < (1 << RB); h++) y0[h] = fp_from_u64(sp[(size_t)((h << RA) + jg) * 1024 + p]);
   }
@@ -1130,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_bsplit_pass0_lds(DevCtx c, const u64 *_
 template <int LOGN>
 __global__ __launch_bounds__(256) void k_bsplit_finish_lds(DevCtx c, const double *__restrict__ half, const double *__restrict__ tco,
                                                            const u64 *__restrict__ addend, size_t addend_stride, int add_c1,
-                                                           u64 *__restrict__ out, int nl) {
+                                                           u64 *__restrict__ out, int nl, u32 ginv /* BFV rotation: gather the addend */) {
   constexpr int R = LOGN - 10, NB = 1 << R, RA = 3, RB = R - RA, P = 32;
   __shared__ double lds[NB * P];
   const int pg = blockIdx.x & 31;
@@ -1191,7 +1200,15 @@ __global__ __launch_bounds__(256) void k_bsplit_finish_lds(DevCtx c, const doubl
       const size_t e = (size_t)((h << RA) + j) * 1024 + p;
       const double d = fp_mul_lazy(y[h], m.inv_n_c, m.inv_n_cq, m.qd) - (tsrc[e] + fix);
       double r = fp_mul_lazy(d, inv, inv_q, m.qd);
-      if (add) r += fp_from_u64(cin[e]);
+      if (add) {
+        if (ginv) {  // workgroup-uniform
+          bool neg;
+          const u64 v = (cin - (size_t)(pg * P))[galois_coef_src((u32)(e + (size_t)(pg * P)), ginv, LOGN, neg)];
+          r += fp_from_u64(neg ? neg_mod(v, m.q) : v);
+        } else {
+          r += fp_from_u64(cin[e]);
+        }
+      }
       o[e] = fp_to_canon(r, m.qd, m.qinv);
     }
   }
@@ -1208,7 +1225,7 @@ bool bsplit_big_applies(const abc_hip_ctx *c, int nl) {
 template <int LOGN>
 static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, size_t cc, int nl, const u64 *target, size_t target_stride,
                             const u64 *key, const u64 *addend, size_t addend_stride, int add_c1, u64 *out, u32 ginv = 0) {
-  if (ginv && LOGN > 14) { set_error("bsplit: the folded BFV permutation is an N <= 2^14 path"); return 1; }
+  if (ginv && LOGN > 14 && c->sw.no_finish_lds) { set_error("bsplit: the folded BFV permutation needs the LDS cross passes on these rings"); return 1; }
   constexpr int NB = 1 << (LOGN - 10);
   const size_t PS = (size_t)c->dc.ps;
   double *part = scratch, *half = part + cc * (size_t)nl * (nl + 1) * PS, *tco = half + cc * 2 * (size_t)(nl + 1) * PS;
@@ -1220,7 +1237,7 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
     hipLaunchKernelGGL((k_bsplit_pass0<LOGN>), dim3((unsigned)(cc * nl * (nl + 1) * 4)), dim3(256), 0, st, c->dc, target, target_stride, part,
                        nl, 0u);
   else
-    hipLaunchKernelGGL((k_bsplit_pass0_lds<LOGN>), dim3((unsigned)(cc * nl * 32)), dim3(256), 0, st, c->dc, target, target_stride, part, nl);
+    hipLaunchKernelGGL((k_bsplit_pass0_lds<LOGN>), dim3((unsigned)(cc * nl * 32)), dim3(256), 0, st, c->dc, target, target_stride, part, nl, ginv);
   const dim3 g((unsigned)(cc * (nl + 1) * NB));
   const size_t lds = (size_t)((nl < 2 ? 2 : nl) * lds_words(10)) * 8;
   if (nl == 8 && !c->sw.no_special8x2) {
@@ -1247,7 +1264,7 @@ static int bsplit_big_chunk(abc_hip_ctx *c, hipStream_t st, double *scratch, siz
                        addend_stride, add_c1, out, nl, 0u);
   else
     hipLaunchKernelGGL((k_bsplit_finish_lds<LOGN>), dim3((unsigned)(cc * 2 * nl * 32)), dim3(256), 0, st, c->dc, half, tco, addend,
-                       addend_stride, add_c1, out, nl);
+                       addend_stride, add_c1, out, nl, ginv);
   ABC_HIP_CHECK(hipGetLastError());
   return 0;
 }
@@ -1275,8 +1292,8 @@ int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u6
       continue;
     }
     const int rc = (c->logn == 15)
-                       ? bsplit_big_chunk<15>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o)
-                       : bsplit_big_chunk<16>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o);
+                       ? bsplit_big_chunk<15>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o, ginv)
+                       : bsplit_big_chunk<16>(c, c->stream, (double *)c->ws, cc, nl, tg, target_stride, key, ad, addend_stride, add_c1 ? 1 : 0, o, ginv);
     if (rc) return rc;
   }
   return 0;
