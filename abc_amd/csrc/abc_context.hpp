@@ -214,7 +214,7 @@ int big_block_log(void);
 int launch_addsub(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out, int nl, size_t polys, int op);  // 0 add 1 sub 2 neg
 int launch_ckks_tensor(abc_hip_ctx *c, const u64 *a, const u64 *b, u64 *out3, int nl, size_t count);
 int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out2, int nl,
-                      size_t count, const u64 *addend, size_t addend_stride, bool add_c1);
+                      size_t count, const u64 *addend, size_t addend_stride, bool add_c1, u32 ginv = 0);
 int launch_ks_tmod(abc_hip_ctx *c, const u64 *prodS, u64 *tmod, int nl, size_t polys);
 int launch_ks_finish(abc_hip_ctx *c, const u64 *prodD, const u64 *tmod, u64 *out, const u64 *addend, size_t addend_stride,
                      bool add_c1, int nl, size_t count);
@@ -259,6 +259,7 @@ void gsplit_main_deep_subset15(hipStream_t st, abc_hip_ctx *c, size_t cc, int nl
                                u32 gelt, u64 imap, int ni);
 bool bsplit_applies(const abc_hip_ctx *c, int nl);
 bool bsplit_big_applies(const abc_hip_ctx *c, int nl);
+bool iks_bfv_applies(const abc_hip_ctx *c, int nl);  // abc_kernels_eval.hip
 int bsplit_big(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out, int nl, size_t count, const u64 *addend,
                size_t addend_stride, bool add_c1, u32 ginv = 0);
 int bsplit_back14(abc_hip_ctx *c, hipStream_t st, size_t cc, int nl, const double *part, double *half, const u64 *key, const u64 *addend,

@@ -190,7 +190,8 @@ int launch_ks_finish(abc_hip_ctx *c, const u64 *prodD, const u64 *tmod, u64 *out
 //                 kernels)                                                                    [one read, 2 / nl of a write]
 // Inner products: canonical operands, one Barrett product per term (a 128-bit accumulator per value would cost 128 VGPRs).
 template <int R>
-__global__ __launch_bounds__(256) void k_iks_pass0(DevCtx c, const u64 *__restrict__ tcoef, size_t tstride, u64 *__restrict__ dec, int nl) {
+__global__ __launch_bounds__(256) void k_iks_pass0(DevCtx c, const u64 *__restrict__ tcoef, size_t tstride, u64 *__restrict__ dec, int nl,
+                                                   u32 ginv /* BFV rotation: elt^-1 mod 2N, the signed permutation folded into the load */) {
   const int G = c.n >> R;
   const int per = G / 256;
   const size_t limb = blockIdx.x / per;  // (ct * nl + J) * (nl + 1) + I
@@ -204,8 +205,19 @@ __global__ __launch_bounds__(256) void k_iks_pass0(DevCtx c, const u64 *__restri
   const NttTable t = ntt_table(c, ki);
   const u64 *__restrict__ src = tcoef + ct * tstride + (size_t)J * c.n + p;
   u64 x[1 << R];
+  if (ginv) {  // workgroup-uniform
+    const u64 *__restrict__ limb = tcoef + ct * tstride + (size_t)J * c.n;
+    const u64 qj = c.mods[J].q;
 #pragma unroll
-  for (int k = 0; k < (1 << R); k++) x[k] = src[(size_t)k * G];
+    for (int k = 0; k < (1 << R); k++) {
+      bool neg;
+      const u64 v = limb[galois_coef_src((u32)(k * G + p), ginv, c.logn, neg)];
+      x[k] = neg ? neg_mod(v, qj) : v;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < (1 << R); k++) x[k] = src[(size_t)k * G];
+  }
 #pragma unroll
   for (int k = 0; k < (1 << R); k++) x[k] = reduce64(x[k], m);
 #pragma unroll
@@ -339,7 +351,7 @@ __global__ __launch_bounds__((1 << LB) / 16, 3) void k_iks_special(DevCtx c, con
 template <int R>
 __global__ __launch_bounds__(256) void k_iks_finish(DevCtx c, const u64 *__restrict__ prodD, const u64 *__restrict__ prodS,
                                                     const u64 *addend, size_t addend_stride, int add_c1, u64 *out /* may be the addend */,
-                                                    int nl) {
+                                                    int nl, u32 ginv /* BFV rotation: gather the addend (then out is not the addend) */) {
   const int G = c.n >> R;
   const int per = G / 256;
   const size_t cc = blockIdx.x / per;  // ct * 2 + comp
@@ -390,35 +402,51 @@ __global__ __launch_bounds__(256) void k_iks_finish(DevCtx c, const u64 *__restr
     for (int k = 0; k < (1 << R); k++) {
       const u64 tm = add_mod(reduce64(t[k], m), fix, m.q);
       u64 v = mul_shoup(sub_mod(scale_inv_n(x[k], m), tm, m.q), inv, inv_s, m.q);
-      if (add) v = add_mod(v, cin[(size_t)k * G], m.q);
+      if (add) {
+        if (ginv) {  // workgroup-uniform
+          bool neg;
+          const u64 a = (cin - p)[galois_coef_src((u32)(k * G + p), ginv, c.logn, neg)];
+          v = add_mod(v, neg ? neg_mod(a, m.q) : a, m.q);
+        } else {
+          v = add_mod(v, cin[(size_t)k * G], m.q);
+        }
+      }
       o[(size_t)k * G] = v;
     }
   }
 }
 static int iks_finish(abc_hip_ctx *c, const u64 *prodD, const u64 *prodS, const u64 *addend, size_t addend_stride, bool add_c1, u64 *out,
-                      int nl, size_t cc) {
+                      int nl, size_t cc, u32 ginv) {
   const int S0 = c->logn - big_block_log();
   const int G = c->n >> S0;
   const dim3 grid((unsigned)(cc * 2 * (G / 256)));
   if (S0 == 3)
-    hipLaunchKernelGGL(k_iks_finish<3>, grid, dim3(256), 0, c->stream, c->dc, prodD, prodS, addend, addend_stride, add_c1 ? 1 : 0, out, nl);
+    hipLaunchKernelGGL(k_iks_finish<3>, grid, dim3(256), 0, c->stream, c->dc, prodD, prodS, addend, addend_stride, add_c1 ? 1 : 0, out, nl, ginv);
   else
-    hipLaunchKernelGGL(k_iks_finish<4>, grid, dim3(256), 0, c->stream, c->dc, prodD, prodS, addend, addend_stride, add_c1 ? 1 : 0, out, nl);
+    hipLaunchKernelGGL(k_iks_finish<4>, grid, dim3(256), 0, c->stream, c->dc, prodD, prodS, addend, addend_stride, add_c1 ? 1 : 0, out, nl, ginv);
   ABC_HIP_CHECK(hipGetLastError());
   return 0;
 }
 
 // 1: error; -1: not applicable (the caller takes the generic kernels); 0: prodS holds the special limb's sums half-way back to
 // coefficients (strided stages left), prodD the data limbs' -- likewise for BFV, in NTT form for CKKS
-static int iks_front(abc_hip_ctx *c, const u64 *tc, size_t tcs, const u64 *key, u64 *dec, u64 *prodD, u64 *prodS, int nl, size_t cc) {
+// BFV with the permutation of a rotation folded in (rotate_fused): the integer sequence must be the one that runs
+bool iks_bfv_applies(const abc_hip_ctx *c, int nl) {
+  if (c->scheme != 1 || (c->logn != 15 && c->logn != 16) || c->sw.no_iks || big_block_log() != 12 || nl < 1) return false;
+  bool fp = c->use_fp;
+  for (int j = 0; j < nl; j++) fp = fp && fp_ok(c->h_mods[j].bits);
+  fp = fp && fp_ok(c->h_mods[c->K - 1].bits);
+  return !fp;  // an all-fp64 decomposition takes launch_ks_expand_ntt_fp + the generic kernels
+}
+static int iks_front(abc_hip_ctx *c, const u64 *tc, size_t tcs, const u64 *key, u64 *dec, u64 *prodD, u64 *prodS, int nl, size_t cc, u32 ginv) {
   if ((c->logn != 15 && c->logn != 16) || c->sw.no_iks) return -1;
   const int S0 = c->logn - big_block_log();
   if (big_block_log() != 12) return -1;
   const size_t limbs = cc * nl * (nl + 1);
   const int G = c->n >> S0;
   const dim3 g0((unsigned)(limbs * (G / 256)));
-  if (S0 == 3) hipLaunchKernelGGL(k_iks_pass0<3>, g0, dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl);
-  else hipLaunchKernelGGL(k_iks_pass0<4>, g0, dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl);
+  if (S0 == 3) hipLaunchKernelGGL(k_iks_pass0<3>, g0, dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl, ginv);
+  else hipLaunchKernelGGL(k_iks_pass0<4>, g0, dim3(256), 0, c->stream, c->dc, tc, tcs, dec, nl, ginv);
   ABC_HIP_CHECK(hipGetLastError());
   const dim3 g1((unsigned)((cc * (nl + 1)) << S0));
   const u64 *keys = key_shoup(c, key);
@@ -443,8 +471,9 @@ static int iks_front(abc_hip_ctx *c, const u64 *tc, size_t tcs, const u64 *key, 
 }
 
 int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, const u64 *key, u64 *out2, int nl, size_t count,
-                      const u64 *addend, size_t addend_stride, bool add_c1) {
+                      const u64 *addend, size_t addend_stride, bool add_c1, u32 ginv) {
   if (!count) return 0;
+  if (ginv && !iks_bfv_applies(c, nl)) { set_error("keyswitch_generic: a folded permutation needs the fused integer sequence"); return 1; }
   const bool ckks = (c->scheme == 2);
   const size_t N = (size_t)c->n;
   // workspace per ciphertext (words): tcoef nl + dec nl(nl+1) + prodD 2nl + prodS 2 + tmod 2nl
@@ -477,10 +506,10 @@ int keyswitch_generic(abc_hip_ctx *c, const u64 *target, size_t target_stride, c
     }
     const int fused_expand = launch_ks_expand_ntt_fp(c, tc, tcs, dec, dmap, nl, cc);
     if (fused_expand > 0) return 1;
-    const int iks = fused_expand < 0 ? iks_front(c, tc, tcs, key, dec, prodD, prodS, nl, cc) : -1;
+    const int iks = fused_expand < 0 ? iks_front(c, tc, tcs, key, dec, prodD, prodS, nl, cc, ginv) : -1;
     if (iks > 0) return 1;
     if (iks == 0 && !ckks) {  // inner products done, block stages of the inverse transforms too: one kernel does the rest
-      if (iks_finish(c, prodD, prodS, addend ? addend + off * addend_stride : nullptr, addend_stride, add_c1, out2 + off * 2 * nl * N, nl, cc))
+      if (iks_finish(c, prodD, prodS, addend ? addend + off * addend_stride : nullptr, addend_stride, add_c1, out2 + off * 2 * nl * N, nl, cc, ginv))
         return 1;
       continue;
     }

@@ -1526,6 +1526,11 @@ int rotate_fused(abc_hip_ctx *c, const u64 *in, u32 elt, const u64 *key, u64 *ou
       return bsplit_big(c, in + pwb, 2 * pwb, key, out, nl, count, in, 2 * pwb, false, (u32)host::invmod(elt, 2 * (uint64_t)c->n));
     }
   }
+  if (c->scheme == 1 && in != out && !c->sw.no_galois_fusion && iks_bfv_applies(c, nl) && !bsplit_big_applies(c, nl)) {
+    if (!count) return 0;  // BFV on a big ring with a prime above 2^50: k_iks_pass0 / k_iks_finish gather
+    const size_t pwb = (size_t)nl * c->n;
+    return keyswitch_generic(c, in + pwb, 2 * pwb, key, out, nl, count, in, 2 * pwb, false, (u32)host::invmod(elt, 2 * (uint64_t)c->n));
+  }
   if (c->logn != 14 || c->scheme != 2 || in == out) return -1;
   if (!all_fp(c) && !isplit_applies(c, nl)) return -1;
   if (c->sw.no_split || c->sw.no_fused || c->sw.no_galois_fusion) return -1;

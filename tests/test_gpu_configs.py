@@ -133,6 +133,11 @@ def test_bfv_wide_chains(n, bits, variant, oracle_mod, capi, monkeypatch):
     got = g.mul_relin(np.stack([a, ex, r]), np.stack([b, a, ex]))
     _eq("N=%d wide-chain batch row 1" % n, got[1], o.mul_relin(ex, a))
     _eq("N=%d wide-chain batch row 2" % n, got[2], o.mul_relin(r, ex))
+    # rotations: on the big ring the signed coefficient permutation is folded into k_iks_pass0 / k_iks_finish
+    _eq("N=%d wide-chain rotate 1, extreme residues" % n, g.rotate(ex, 1), o.rotate(ex, 1))
+    rot = g.rotate(np.stack([a, ex, r]), -7)  # needs the NAF decomposition: three key switches
+    _eq("N=%d wide-chain batched rotate -7 [1]" % n, rot[1], o.rotate(ex, -7))
+    _eq("N=%d wide-chain batched rotate -7 [2]" % n, rot[2], o.rotate(r, -7))
 
 
 @pytest.mark.parametrize("generic", [False, True, "unfused_multiply", "multiply_on_4096_point_blocks"])
